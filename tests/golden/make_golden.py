@@ -1,0 +1,290 @@
+"""Generate golden vectors by running the REFERENCE itself (CPU, this container only).
+
+Usage (build container, where /root/reference exists):
+    python tests/golden/make_golden.py
+
+The reference never travels to the GPU box; only the small ``*.safetensors`` /
+``*.json`` fixtures written next to this script do.  The harness follows
+SURVEY.md section 8c:
+  * register an empty ``sparsify`` package whose ``__path__`` is the reference dir
+    (bypasses ``sparsify/__init__`` -> trainer -> schedulefree for the op goldens),
+  * in-memory import stand-ins for the absent ``simple_parsing`` / ``natsort`` /
+    ``schedulefree`` (dataclass plumbing only, no arithmetic),
+  * SPARSIFY_NO_COMPILE=1, TRITON_INTERPRET=1 (the encoder grad-W Triton kernel
+    then runs on CPU), eager decoder via SPARSIFY_DISABLE_TRITON=1,
+  * ``ForwardOutput`` constructor that drops the two stray positional zeros of
+    sparse_coder.py:196-205 (reference bug).
+"""
+import dataclasses
+import json
+import os
+import sys
+import types
+from dataclasses import replace
+from pathlib import Path
+
+os.environ["SPARSIFY_NO_COMPILE"] = "1"
+os.environ["SPARSIFY_DISABLE_TRITON"] = "1"
+os.environ["TRITON_INTERPRET"] = "1"
+
+REF = "/root/reference"
+OUT = Path(__file__).resolve().parent
+
+
+def install_harness():
+    pkg = types.ModuleType("sparsify")
+    pkg.__path__ = [f"{REF}/sparsify"]
+    sys.modules["sparsify"] = pkg
+
+    sp = types.ModuleType("simple_parsing")
+
+    class Serializable:
+        def to_dict(self):
+            return dataclasses.asdict(self)
+
+        @classmethod
+        def from_dict(cls, d, drop_extra_fields=False):
+            names = {f.name for f in dataclasses.fields(cls)}
+            return cls(**{k: v for k, v in d.items() if k in names})
+
+    def list_field(*a, **k):
+        return dataclasses.field(default_factory=lambda: list(a))
+
+    sp.Serializable = Serializable
+    sp.list_field = list_field
+    sp.field = dataclasses.field
+    sys.modules["simple_parsing"] = sp
+
+    ns = types.ModuleType("natsort")
+    ns.natsorted = sorted
+    sys.modules["natsort"] = ns
+
+    sf = types.ModuleType("schedulefree")
+    sf.ScheduleFreeWrapper = type("ScheduleFreeWrapper", (), {})
+    sf.ScheduleFreeWrapperReference = type("ScheduleFreeWrapperReference", (), {})
+    sys.modules["schedulefree"] = sf
+
+
+install_harness()
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+import sparsify.sparse_coder as ref_sc  # noqa: E402
+from sparsify.config import SparseCoderConfig  # noqa: E402
+from sparsify.fused_encoder import fused_encoder  # noqa: E402
+from sparsify.kernels import triton_sparse_transpose_dense_matmul  # noqa: E402
+from sparsify.runner import CrossLayerRunner  # noqa: E402
+from sparsify.sparse_coder import SparseCoder  # noqa: E402
+from sparsify.utils import eager_decode  # noqa: E402
+from sparsify.xformers import xformers_embedding_bag  # noqa: E402
+
+_RefForwardOutput = ref_sc.ForwardOutput
+
+
+def _forward_output(sae_out, latent_acts, latent_indices, fvu, *rest):
+    # sparse_coder.py:196-205 passes 7 positionals to a 5-field dataclass.
+    return _RefForwardOutput(sae_out, latent_acts, latent_indices, fvu, bool(rest[-1]) if rest else False)
+
+
+ref_sc.ForwardOutput = _forward_output
+
+
+def save(name, tensors, meta):
+    tensors = {k: v.detach().contiguous().clone() for k, v in tensors.items()}
+    save_file(tensors, str(OUT / f"{name}.safetensors"))
+    with open(OUT / f"{name}.json", "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote", name, sum(t.numel() * t.element_size() for t in tensors.values()), "bytes")
+
+
+def canon(vals, idx):
+    """Canonical order for an unsorted top-k: value desc, index asc."""
+    o1 = torch.argsort(idx, dim=1, stable=True)
+    v1, i1 = torch.gather(vals, 1, o1), torch.gather(idx, 1, o1)
+    o2 = torch.argsort(v1, dim=1, descending=True, stable=True)
+    return torch.gather(v1, 1, o2), torch.gather(i1, 1, o2), torch.gather(o1, 1, o2)
+
+
+# ---------------------------------------------------------------- encoder
+def golden_encoder(name, N, d, M, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, d, generator=g).requires_grad_()
+    W = (torch.randn(M, d, generator=g) / d**0.5).requires_grad_()
+    b = (0.1 * torch.randn(M, generator=g)).requires_grad_()
+    up = torch.randn(N, k, generator=g)
+    out = fused_encoder(x, W, b, k, "topk")
+    vals, idx = out.top_acts, out.top_indices
+    # loss 1: sum of values (tests/test_encode.py:46)
+    vals.sum().backward(retain_graph=True)
+    g1 = dict(gx=x.grad.clone(), gW=W.grad.clone(), gb=b.grad.clone())
+    x.grad = W.grad = b.grad = None
+    cv, ci, perm = canon(vals.detach(), idx)
+    # loss 2: random upstream grad, expressed in canonical order
+    (vals * torch.zeros_like(vals).scatter_(1, perm, up)).sum().backward()
+    g2 = dict(gx=x.grad.clone(), gW=W.grad.clone(), gb=b.grad.clone())
+    save(
+        name,
+        dict(x=x, W=W, b=b, up=up, vals=cv, idx=ci,
+             gx_sum=g1["gx"], gW_sum=g1["gW"], gb_sum=g1["gb"],
+             gx_up=g2["gx"], gW_up=g2["gW"], gb_up=g2["gb"]),
+        dict(N=N, d=d, M=M, k=k, seed=seed, ref="fused_encoder.py:293-422"),
+    )
+
+
+# ---------------------------------------------------------------- decoder
+def golden_decoder(name, N, d, M, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    W = torch.randn(M, d, generator=g).requires_grad_()
+    lat = torch.rand(N, M, generator=g)
+    acts, idx = lat.topk(k)
+    acts = acts.clone().requires_grad_()
+    G = torch.randn(N, d, generator=g)
+    y = eager_decode(idx, acts, W)
+    y.backward(G)
+    gW_e, ga_e = W.grad.clone(), acts.grad.clone()
+    W.grad = acts.grad = None
+    y2 = xformers_embedding_bag(idx, W, acts)  # Triton kernels under the interpreter
+    y2.backward(G)
+    spt = triton_sparse_transpose_dense_matmul(idx, acts.detach().float(), G, N=M)
+    save(
+        name,
+        dict(W=W, acts=acts, idx=idx, G=G, y=y, gW=gW_e, gacts=ga_e,
+             y_xf=y2, gW_xf=W.grad, gacts_xf=acts.grad, spT=spt),
+        dict(N=N, d=d, M=M, k=k, seed=seed, ref="utils.py:442-457; xformers.py; kernels.py:14-54"),
+    )
+
+
+# ---------------------------------------------------------------- single layer
+def warm(sae, g):
+    """Non-trivial parameter values (transcoder decoders start at zero)."""
+    with torch.no_grad():
+        for n, p in sae.named_parameters():
+            if n.startswith("encoder"):
+                continue
+            if "post_enc_scale" in n:
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif "post_enc" in n:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            elif "W_dec" in n:
+                p.copy_(torch.randn(p.shape, generator=g) / p.shape[1] ** 0.5)
+            elif "W_skip" in n:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g) / p.shape[1] ** 0.5)
+            elif "b_dec" in n:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        sae.encoder.bias.copy_(0.05 * torch.randn(sae.encoder.bias.shape, generator=g))
+        if hasattr(sae, "in_norm"):
+            sae.in_norm.fill_(1.7)
+            sae.out_norm.fill_(2.3)
+
+
+def golden_single(name, cfg_kw, N, d, seed, masked):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    cfg = SparseCoderConfig(**cfg_kw)
+    sae = SparseCoder(d, cfg, dtype=torch.float32)
+    warm(sae, g)
+    if not cfg.transcode and cfg.normalize_decoder:
+        sae.set_decoder_norm_to_unit_norm()
+    x = torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)
+    y = x if not cfg.transcode else torch.randn(N, d, generator=g)
+    mask = None
+    if masked:
+        mask = torch.ones(N, dtype=torch.bool)
+        mask[::5] = False
+    params = {f"p.{n}": p.detach().clone() for n, p in sae.named_parameters()}
+    for n, b_ in sae.named_buffers():
+        params[f"p.{n}"] = b_.detach().clone()
+    runner = CrossLayerRunner()
+    enc = runner.encode(x, sae)
+    out = runner.decode(enc, y, module_name="l0", detach_grad=True, loss_mask=mask)
+    out.fvu.backward()
+    runner.restore()
+    cv, ci, _ = canon(enc.latent_acts.detach(), enc.latent_indices)
+    t = dict(x=x, y=y, fvu=out.fvu.detach(), sae_out=out.sae_out.detach(), vals=cv, idx=ci, **params)
+    if mask is not None:
+        t["mask"] = mask
+    for n, p in sae.named_parameters():
+        if p.grad is not None:
+            t[f"g.{n}"] = p.grad.clone()
+    if not cfg.transcode:
+        sae.remove_gradient_parallel_to_decoder_directions()
+        t["g_proj.W_dec"] = sae.W_dec.grad.clone()
+    save(name, t, dict(cfg=cfg_kw, N=N, d=d, seed=seed, masked=masked,
+                       ref="sparse_coder.py:143-229,632-685; runner.py:25-201"))
+
+
+# ---------------------------------------------------------------- CLT
+def golden_clt(name, cfg_kw, L, cross, N, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    base = SparseCoderConfig(**cfg_kw)
+    saes = []
+    sources = []
+    for pos in range(L):  # trainer.py:117-146
+        torch.manual_seed(0)
+        n_targets = min(cross, L - pos)
+        sources.append(pos + n_targets)
+        while sources[0] < pos:
+            sources.pop(0)
+        cfg = replace(base, n_targets=n_targets, n_sources=len(sources))
+        sae = SparseCoder(d, cfg, dtype=torch.float32)
+        warm(sae, g)
+        saes.append(sae)
+    mask = torch.ones(N, dtype=torch.bool)
+    mask[::7] = False
+    t = dict(mask=mask)
+    xs, ys = [], []
+    for l in range(L):
+        x = torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)
+        y = 0.5 * x + torch.randn(N, d, generator=g)
+        xs.append(x)
+        ys.append(y)
+        t[f"x.{l}"], t[f"y.{l}"] = x, y
+        for n, p in saes[l].named_parameters():
+            t[f"p.{l}.{n}"] = p.detach().clone()
+        for n, b_ in saes[l].named_buffers():
+            t[f"p.{l}.{n}"] = b_.detach().clone()
+    runner = CrossLayerRunner()
+    for l in range(L):  # trainer.py:598-682
+        enc = runner.encode(xs[l], saes[l])
+        out = runner.decode(enc, ys[l], module_name=f"layers.{l}", detach_grad=True, loss_mask=mask)
+        t[f"fvu.{l}"] = out.fvu.detach().clone()
+        t[f"sae_out.{l}"] = out.sae_out.detach().clone()
+        cv, ci, _ = canon(enc.original_activations.detach() if hasattr(enc, "original_activations")
+                          else enc.latent_acts.detach(), enc.latent_indices)
+        t[f"vals.{l}"], t[f"idx.{l}"] = cv, ci
+        out.fvu.backward()
+        runner.restore()
+    assert len(runner.outputs) == 0
+    for l in range(L):
+        for n, p in saes[l].named_parameters():
+            assert p.grad is not None, (l, n)
+            t[f"g.{l}.{n}"] = p.grad.clone()
+    save(name, t, dict(cfg=cfg_kw, L=L, cross_layer=cross, N=N, d=d, seed=seed,
+                       ref="runner.py:25-201; trainer.py:117-146,598-682"))
+
+
+def main():
+    golden_encoder("encoder_a", N=32, d=48, M=512, k=8, seed=1)
+    golden_encoder("encoder_b", N=16, d=64, M=256, k=32, seed=2)
+    golden_decoder("decoder_d48", N=2, d=48, M=128, k=10, seed=3)  # tests/test_decode.py shapes
+    golden_decoder("decoder_d64", N=2, d=64, M=128, k=10, seed=4)
+    golden_decoder("decoder_c", N=24, d=40, M=64, k=6, seed=5)
+    golden_single("single_transcoder_skip", dict(expansion_factor=8, k=8, transcode=True, skip_connection=True),
+                  N=40, d=32, seed=6, masked=True)
+    golden_single("single_transcoder_scale_norm",
+                  dict(expansion_factor=8, k=4, transcode=True, skip_connection=True,
+                       post_encoder_scale=True, normalize_io=True), N=30, d=24, seed=7, masked=False)
+    golden_single("single_sae", dict(expansion_factor=8, k=8, transcode=False), N=40, d=32, seed=8, masked=True)
+    golden_clt("clt_none_L3", dict(expansion_factor=8, k=4, transcode=True, skip_connection=True),
+               L=3, cross=3, N=28, d=24, seed=9)
+    golden_clt("clt_none_div_scale_norm_L4",
+               dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, divide_cross_layer=True,
+                    post_encoder_scale=True, normalize_io=True), L=4, cross=3, N=28, d=24, seed=10)
+    golden_clt("clt_concat_L3",
+               dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, coalesce_topk="concat",
+                    post_encoder_scale=True, normalize_io=True), L=3, cross=3, N=28, d=24, seed=11)
+
+
+if __name__ == "__main__":
+    main()
