@@ -1,0 +1,80 @@
+"""Multi-tensor Adam on the HIP kernel `clt_adam_step` -- the MI355X counterpart of the
+``torch.optim.Adam(pgs, betas=(b1, b2))`` the reference builds in trainer.py:166-186
+(eps 1e-8, no weight decay, no amsgrad; per-group lr, possibly a tensor; LambdaLR-compatible).
+
+One launch updates every parameter of every group: the host refreshes a small table of
+(p, g, m, v, numel, lr) records each step (grad pointers change when autograd allocates
+new .grad tensors) and uploads it asynchronously; the chunk -> tensor map is static."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hip_ops import _DT, _stream
+
+CHUNK = 1 << 16
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        defaults = dict(lr=lr, betas=betas, eps=eps)
+        super().__init__(params, defaults)
+        self._step = 0
+        self._tables = {}  # key: tuple of param ids with grads -> static device tables
+
+    def _state(self, p):
+        st = self.state[p]
+        if not st:
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        self._step += 1
+        live = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is not None:
+                    live.append((gi, p))
+        if not live:
+            return
+        betas = self.param_groups[0]["betas"]
+        eps = self.param_groups[0]["eps"]
+        dev = live[0][1].device
+        key = tuple(id(p) for _, p in live)
+        tb = self._tables.get(key)
+        if tb is None:
+            ct, cs = [], []
+            for ti, (_, p) in enumerate(live):
+                n = p.numel()
+                starts = np.arange(0, n, CHUNK, dtype=np.int64)
+                ct.append(np.full(len(starts), ti, dtype=np.int32))
+                cs.append(starts)
+            ct = torch.from_numpy(np.concatenate(ct)).to(dev)
+            cs = torch.from_numpy(np.concatenate(cs)).to(dev)
+            host = torch.empty(len(live) * C.sizeof(_lib.AdamTensor), dtype=torch.uint8).pin_memory()
+            devt = torch.empty_like(host, device=dev)
+            tb = self._tables[key] = (ct, cs, host, devt)
+        ct, cs, host, devt = tb
+        recs = (_lib.AdamTensor * len(live)).from_address(host.data_ptr())
+        for ti, (gi, p) in enumerate(live):
+            g = p.grad
+            if not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            assert p.is_contiguous() and g.shape == p.shape
+            st = self._state(p)
+            r = recs[ti]
+            r.p, r.g, r.m, r.v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            r.numel = p.numel()
+            r.lr = float(self.param_groups[gi]["lr"])
+            r.p_dtype, r.g_dtype = _DT[p.dtype], _DT[g.dtype]
+        devt.copy_(host, non_blocking=True)
+        _lib.check(
+            _lib.load().clt_adam_step(C.c_void_p(devt.data_ptr()), len(live), C.c_void_p(ct.data_ptr()),
+                                      C.c_void_p(cs.data_ptr()), ct.numel(), CHUNK, 1.0, float(betas[0]), float(betas[1]),
+                                      float(eps), self._step, _stream(devt)), "clt_adam_step")

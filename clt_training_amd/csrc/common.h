@@ -1,0 +1,114 @@
+// Shared helpers for the gfx950 kernels of libcltmi355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/clt_mi355.h"
+
+#define CLT_WAVE 64
+
+typedef __bf16 bf16_t;
+
+namespace clt {
+
+void set_error(const char* fmt, ...);
+
+#define CLT_CHECK_ARG(cond, ...)         \
+  do {                                   \
+    if (!(cond)) {                       \
+      clt::set_error(__VA_ARGS__);       \
+      return CLT_ERR_BAD_ARG;            \
+    }                                    \
+  } while (0)
+
+#define CLT_UNSUPPORTED(cond, ...)       \
+  do {                                   \
+    if (!(cond)) {                       \
+      clt::set_error(__VA_ARGS__);       \
+      return CLT_ERR_UNSUPPORTED;        \
+    }                                    \
+  } while (0)
+
+#define CLT_CHECK_LAUNCH(name)                                                    \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      clt::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return CLT_ERR_LAUNCH;                                                      \
+    }                                                                             \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t dtype_size(int dt) { return dt == CLT_BF16 ? 2 : 4; }
+static inline bool valid_dtype(int dt) { return dt == CLT_F32 || dt == CLT_BF16; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  bf16_t b = (bf16_t)f;  // v_cvt_pk_bf16_f32: round to nearest even, NaN preserving
+  return (uint32_t)__builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+// 16-byte chunk of a row, as 8 bf16 or 4 f32, expanded to floats.
+template <typename T>
+struct Chunk;
+template <>
+struct Chunk<bf16_t> {
+  static constexpr int E = 8;
+  __device__ static __forceinline__ void load(const void* p, float (&f)[8]) {
+    uint4 u = *reinterpret_cast<const uint4*>(p);
+    f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+    f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+  }
+  __device__ static __forceinline__ void expand(const uint4& u, float (&f)[8]) {
+    f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+    f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+  }
+  __device__ static __forceinline__ void store(void* p, const float (&f)[8]) {
+    uint4 u;
+    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+    u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+  }
+};
+template <>
+struct Chunk<float> {
+  static constexpr int E = 4;
+  __device__ static __forceinline__ void load(const void* p, float (&f)[4]) {
+    float4 u = *reinterpret_cast<const float4*>(p);
+    f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w;
+  }
+  __device__ static __forceinline__ void expand(const uint4& u, float (&f)[4]) {
+    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y);
+    f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+  }
+  __device__ static __forceinline__ void store(void* p, const float (&f)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+};
+
+__device__ __forceinline__ float load_scalar(const void* p, int dtype, int64_t i) {
+  if (dtype == CLT_BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+  return reinterpret_cast<const float*>(p)[i];
+}
+
+__device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace clt

@@ -1,0 +1,341 @@
+// Sparse decoder (embedding bag) forward and grad-wrt-activations for gfx950.
+//
+// Layout: one 64-lane wave per token.  A weight row is d*sizeof(WT) bytes = a
+// whole number of 16-byte chunks; lane l owns chunks l, l+64, l+128, ... (CH of
+// them), so every wave-load is a contiguous, fully coalesced run of up to 1 KiB
+// of one row.  U rows are kept in flight per wave to cover HBM latency
+// (MI355X_MICROARCH.md, "Indexed rows": gathered whole rows into registers reach
+// 5.5-5.8 TB/s with one wave per destination and >= 4 rows in flight).
+// HBM-bound: algorithmic bytes per token = (k + 1) * d * sizeof(WT).
+#include "common.h"
+
+namespace clt {
+
+template <typename GT, int E>
+__device__ __forceinline__ void load_elems(const GT* p, float (&f)[E]);
+
+template <>
+__device__ __forceinline__ void load_elems<bf16_t, 8>(const bf16_t* p, float (&f)[8]) {
+  Chunk<bf16_t>::load(p, f);
+}
+template <>
+__device__ __forceinline__ void load_elems<float, 4>(const float* p, float (&f)[4]) {
+  Chunk<float>::load(p, f);
+}
+template <>
+__device__ __forceinline__ void load_elems<float, 8>(const float* p, float (&f)[8]) {
+  float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load_elems<bf16_t, 4>(const bf16_t* p, float (&f)[4]) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+}
+
+template <typename OT, int E>
+__device__ __forceinline__ void store_elems(OT* p, const float (&f)[E]);
+template <>
+__device__ __forceinline__ void store_elems<bf16_t, 8>(bf16_t* p, const float (&f)[8]) {
+  Chunk<bf16_t>::store(p, f);
+}
+template <>
+__device__ __forceinline__ void store_elems<float, 4>(float* p, const float (&f)[4]) {
+  Chunk<float>::store(p, f);
+}
+template <>
+__device__ __forceinline__ void store_elems<float, 8>(float* p, const float (&f)[8]) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <>
+__device__ __forceinline__ void store_elems<bf16_t, 4>(bf16_t* p, const float (&f)[4]) {
+  uint2 u;
+  u.x = pack_bf16x2(f[0], f[1]);
+  u.y = pack_bf16x2(f[2], f[3]);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+// a' = (v + post_enc[idx] * (v > 0)) * post_scale[idx]   (sparse_coder.py:136-140)
+__device__ __forceinline__ float post_affine(float v, int r, const float* post_enc, const float* post_scale) {
+  float a = v;
+  if (post_enc) a += (v > 0.f) ? post_enc[r] : 0.f;
+  if (post_scale) a *= post_scale[r];
+  return a;
+}
+
+template <typename WT, typename OT, int CH, int U>
+__global__ __launch_bounds__(256) void decode_fwd_kernel(const int64_t* __restrict__ idx, const void* __restrict__ v,
+                                                         int v_dtype, const float* __restrict__ post_enc,
+                                                         const float* __restrict__ post_scale,
+                                                         const WT* __restrict__ W, int d,
+                                                         const float* __restrict__ bias, OT* out, int flags,
+                                                         float* __restrict__ acts_out, int64_t N, int k) {
+  constexpr int E = Chunk<WT>::E;
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;  // wave-uniform
+  const int nchunks = d / E;
+  float acc[CH][E];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+
+  for (int j0 = 0; j0 < k; j0 += 64) {
+    const int j = j0 + lane;
+    int my_r = 0;
+    float my_a = 0.f;
+    if (j < k) {
+      my_r = (int)idx[n * k + j];
+      float vv = load_scalar(v, v_dtype, n * k + j);
+      float a = post_affine(vv, my_r, post_enc, post_scale);
+      if (flags & CLT_DECODE_ROUND_ACTS) a = bf16_bits_to_f32(f32_to_bf16_bits(a));
+      my_a = a;
+      if (acts_out) acts_out[n * k + j] = a;
+    }
+    const int cnt = min(64, k - j0);
+    for (int jj = 0; jj < cnt; jj += U) {
+      uint4 raw[U][CH];
+      float a_u[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jl = min(jj + u, cnt - 1);
+        const int r = readlane_i(my_r, jl);
+        a_u[u] = (jj + u < cnt) ? readlane_f(my_a, jl) : 0.f;
+        const char* row = reinterpret_cast<const char*>(W) + (size_t)r * (size_t)d * sizeof(WT);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            float w[E];
+            Chunk<WT>::expand(raw[u][c], w);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[c][e] = fmaf(a_u[u], w[e], acc[c][e]);
+          }
+        }
+      }
+    }
+  }
+
+  OT* orow = out + n * (int64_t)d;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      if (bias) {
+        float b[E];
+        load_elems<float, E>(bias + ch * E, b);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[c][e] += b[e];
+      }
+      if (flags & CLT_DECODE_ACCUMULATE) {
+        float o[E];
+        load_elems<OT, E>(orow + ch * E, o);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[c][e] += o[e];
+      }
+      store_elems<OT, E>(orow + ch * E, acc[c]);
+    }
+  }
+}
+
+template <typename WT, typename GT, int CH, int U>
+__global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
+    const int64_t* __restrict__ idx, const void* __restrict__ v, int v_dtype, const float* __restrict__ post_enc,
+    const float* __restrict__ post_scale, const WT* __restrict__ W, int d, const GT* __restrict__ G,
+    float* grad_acts, int accumulate, float* __restrict__ e_post, float* __restrict__ e_scale, int64_t N, int k) {
+  constexpr int E = Chunk<WT>::E;
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int nchunks = d / E;
+  float g[CH][E];
+  const GT* grow = G + n * (int64_t)d;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      load_elems<GT, E>(grow + ch * E, g[c]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) g[c][e] = 0.f;
+    }
+  }
+
+  for (int j0 = 0; j0 < k; j0 += 64) {
+    const int j = j0 + lane;
+    int my_r = 0;
+    if (j < k) my_r = (int)idx[n * k + j];
+    float my_ga = 0.f;
+    const int cnt = min(64, k - j0);
+    for (int jj = 0; jj < cnt; jj += U) {
+      uint4 raw[U][CH];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jl = min(jj + u, cnt - 1);
+        const int r = readlane_i(my_r, jl);
+        const char* row = reinterpret_cast<const char*>(W) + (size_t)r * (size_t)d * sizeof(WT);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            float w[E];
+            Chunk<WT>::expand(raw[u][c], w);
+#pragma unroll
+            for (int e = 0; e < E; ++e) part = fmaf(g[c][e], w[e], part);
+          }
+        }
+        part = wave_sum(part);
+        if (jj + u < cnt && lane == jj + u) my_ga = part;
+      }
+    }
+    if (j < k) {
+      const int64_t o = n * k + j;
+      const float vv = load_scalar(v, v_dtype, o);
+      const float pos = vv > 0.f ? 1.f : 0.f;
+      const float u_ = post_scale ? my_ga * post_scale[my_r] : my_ga;
+      if (e_scale) e_scale[o] = my_ga * (vv + (post_enc ? post_enc[my_r] * pos : 0.f));
+      if (e_post) e_post[o] = u_ * pos;
+      grad_acts[o] = accumulate ? grad_acts[o] + u_ : u_;
+    }
+  }
+}
+
+static int pick_ch(int d, int E) {
+  int chunks = d / E;
+  int ch = (chunks + 63) / 64;
+  if (ch <= 1) return 1;
+  if (ch <= 2) return 2;
+  if (ch <= 4) return 4;
+  if (ch <= 8) return 8;
+  if (ch <= 16) return 16;
+  return -1;
+}
+
+}  // namespace clt
+
+using namespace clt;
+
+template <typename WT, typename OT>
+static int launch_decode_fwd(int ch, dim3 grid, hipStream_t st, const int64_t* idx, const void* v, int v_dtype,
+                             const float* pe, const float* ps, const void* W, int d, const float* bias, void* out,
+                             int flags, float* acts_out, int64_t N, int k) {
+#define LAUNCH(CH, U)                                                                                            \
+  hipLaunchKernelGGL((decode_fwd_kernel<WT, OT, CH, U>), grid, dim3(256), 0, st, idx, v, v_dtype, pe, ps,        \
+                     (const WT*)W, d, bias, (OT*)out, flags, acts_out, N, k)
+  switch (ch) {
+    case 1: LAUNCH(1, 8); break;
+    case 2: LAUNCH(2, 8); break;
+    case 4: LAUNCH(4, 4); break;
+    case 8: LAUNCH(8, 2); break;
+    case 16: LAUNCH(16, 1); break;
+    default: return CLT_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH
+  return CLT_OK;
+}
+
+extern "C" int clt_decode_fwd(const int64_t* idx, const void* v, int v_dtype, const float* post_enc,
+                              const float* post_scale, const void* W, int w_dtype, int64_t M, int d,
+                              const float* bias, void* out, int out_dtype, int flags, float* acts_out, int64_t N,
+                              int k, clt_stream_t stream) {
+  CLT_CHECK_ARG(idx && v && W && out, "clt_decode_fwd: null pointer");
+  CLT_CHECK_ARG(N >= 0 && k > 0 && d > 0 && M > 0 && M < (1ll << 31), "clt_decode_fwd: bad sizes N=%lld k=%d d=%d M=%lld",
+                (long long)N, k, d, (long long)M);
+  CLT_CHECK_ARG(valid_dtype(v_dtype) && valid_dtype(w_dtype) && valid_dtype(out_dtype), "clt_decode_fwd: bad dtype");
+  CLT_CHECK_ARG(aligned16(W) && aligned16(out) && (!bias || aligned16(bias)), "clt_decode_fwd: pointers must be 16-byte aligned");
+  const int E = w_dtype == CLT_BF16 ? 8 : 4;
+  CLT_UNSUPPORTED(d % 8 == 0 || (d % 4 == 0 && w_dtype == CLT_F32 && out_dtype == CLT_F32),
+                  "clt_decode_fwd: d=%d must be a multiple of 8 (or 4 for all-fp32)", d);
+  const int ch = pick_ch(d, E);
+  CLT_UNSUPPORTED(ch > 0, "clt_decode_fwd: d=%d too wide", d);
+  if (N == 0) return CLT_OK;
+  dim3 grid((unsigned)((N + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (w_dtype == CLT_BF16 && out_dtype == CLT_BF16)
+    rc = launch_decode_fwd<bf16_t, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, bias, out, flags, acts_out, N, k);
+  else if (w_dtype == CLT_BF16 && out_dtype == CLT_F32)
+    rc = launch_decode_fwd<bf16_t, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, bias, out, flags, acts_out, N, k);
+  else if (w_dtype == CLT_F32 && out_dtype == CLT_F32)
+    rc = launch_decode_fwd<float, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, bias, out, flags, acts_out, N, k);
+  else
+    rc = launch_decode_fwd<float, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, bias, out, flags, acts_out, N, k);
+  if (rc != CLT_OK) {
+    set_error("clt_decode_fwd: unsupported width d=%d", d);
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_decode_fwd");
+  return CLT_OK;
+}
+
+template <typename WT, typename GT>
+static int launch_decode_bwd(int ch, dim3 grid, hipStream_t st, const int64_t* idx, const void* v, int v_dtype,
+                             const float* pe, const float* ps, const void* W, int d, const void* G, float* ga,
+                             int accumulate, float* e_post, float* e_scale, int64_t N, int k) {
+#define LAUNCH(CH, U)                                                                                            \
+  hipLaunchKernelGGL((decode_bwd_acts_kernel<WT, GT, CH, U>), grid, dim3(256), 0, st, idx, v, v_dtype, pe, ps,   \
+                     (const WT*)W, d, (const GT*)G, ga, accumulate, e_post, e_scale, N, k)
+  switch (ch) {
+    case 1: LAUNCH(1, 8); break;
+    case 2: LAUNCH(2, 8); break;
+    case 4: LAUNCH(4, 4); break;
+    case 8: LAUNCH(8, 2); break;
+    case 16: LAUNCH(16, 1); break;
+    default: return CLT_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH
+  return CLT_OK;
+}
+
+extern "C" int clt_decode_bwd_acts(const int64_t* idx, const void* v, int v_dtype, const float* post_enc,
+                                   const float* post_scale, const void* W, int w_dtype, int64_t M, int d,
+                                   const void* G, int g_dtype, float* grad_acts, int accumulate_grad_acts,
+                                   float* e_post, float* e_scale, int64_t N, int k, clt_stream_t stream) {
+  CLT_CHECK_ARG(idx && v && W && G && grad_acts, "clt_decode_bwd_acts: null pointer");
+  CLT_CHECK_ARG(N >= 0 && k > 0 && d > 0 && M > 0 && M < (1ll << 31), "clt_decode_bwd_acts: bad sizes");
+  CLT_CHECK_ARG(valid_dtype(v_dtype) && valid_dtype(w_dtype) && valid_dtype(g_dtype), "clt_decode_bwd_acts: bad dtype");
+  CLT_CHECK_ARG(aligned16(W) && aligned16(G), "clt_decode_bwd_acts: pointers must be 16-byte aligned");
+  CLT_CHECK_ARG(!e_scale || post_scale, "clt_decode_bwd_acts: e_scale requires post_scale");
+  const int E = w_dtype == CLT_BF16 ? 8 : 4;
+  CLT_UNSUPPORTED(d % 8 == 0 || (d % 4 == 0 && w_dtype == CLT_F32 && g_dtype == CLT_F32),
+                  "clt_decode_bwd_acts: d=%d must be a multiple of 8 (or 4 for all-fp32)", d);
+  const int ch = pick_ch(d, E);
+  CLT_UNSUPPORTED(ch > 0, "clt_decode_bwd_acts: d=%d too wide", d);
+  if (N == 0) return CLT_OK;
+  dim3 grid((unsigned)((N + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (w_dtype == CLT_BF16 && g_dtype == CLT_BF16)
+    rc = launch_decode_bwd<bf16_t, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
+  else if (w_dtype == CLT_BF16 && g_dtype == CLT_F32)
+    rc = launch_decode_bwd<bf16_t, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
+  else if (w_dtype == CLT_F32 && g_dtype == CLT_F32)
+    rc = launch_decode_bwd<float, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
+  else
+    rc = launch_decode_bwd<float, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
+  if (rc != CLT_OK) {
+    set_error("clt_decode_bwd_acts: unsupported width d=%d", d);
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_decode_bwd_acts");
+  return CLT_OK;
+}

@@ -1,0 +1,177 @@
+// FVU loss forward + gradient for gfx950 (sparse_coder.py:207-221).
+//   fvu = sum (m (y - yhat))^2 / sum m (y - ybar_m)^2,   G = gscale * (-2 / tv) * m * (y - yhat)
+// Four small launches, all deterministic two-stage reductions (no atomics):
+//   1 column sums of m*y per row block   2 mean[d]   3 per-block (l2, tv)   4 finalize + write G.
+// HBM-bound, algorithmic bytes ~ N*d*(3*sizeof(y) + 2*sizeof(yhat) + sizeof(G)).
+#include "common.h"
+
+namespace clt {
+
+struct FvuWs {
+  float* pcol;   // [NB][d]
+  float* pcnt;   // [NB]
+  float* mean;   // [d] then count at mean[d]
+  float* psc;    // [NB][2]
+  int NB;
+  int64_t rpb;
+};
+
+static int fvu_blocks(int64_t N) {
+  int64_t nb = (N + 15) / 16;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+__device__ __forceinline__ float ld(const void* p, int dt, int64_t i) { return load_scalar(p, dt, i); }
+
+__global__ __launch_bounds__(256) void fvu_colsum_kernel(const void* __restrict__ y, int y_dtype,
+                                                         const uint8_t* __restrict__ mask, int64_t N, int d,
+                                                         int64_t rpb, float* __restrict__ pcol,
+                                                         float* __restrict__ pcnt) {
+  const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(N, r0 + rpb);
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
+      s += m * ld(y, y_dtype, r * d + c);
+    }
+    pcol[(int64_t)blockIdx.x * d + c] = s;
+  }
+  if (threadIdx.x == 0) {
+    float cnt = 0.f;
+    for (int64_t r = r0; r < r1; ++r) cnt += mask ? (mask[r] ? 1.f : 0.f) : 1.f;
+    pcnt[blockIdx.x] = cnt;
+  }
+}
+
+__global__ void fvu_mean_kernel(const float* __restrict__ pcol, const float* __restrict__ pcnt, int NB, int d,
+                                float* __restrict__ mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  float cnt = 0.f;
+  for (int b = 0; b < NB; ++b) cnt += pcnt[b];
+  if (c < d) {
+    float s = 0.f;
+    for (int b = 0; b < NB; ++b) s += pcol[(int64_t)b * d + c];
+    mean[c] = s / cnt;
+  }
+  if (c == 0) mean[d] = cnt;
+}
+
+__global__ __launch_bounds__(256) void fvu_partial_kernel(const void* __restrict__ y, int y_dtype,
+                                                          const void* __restrict__ yhat, int yh_dtype,
+                                                          const uint8_t* __restrict__ mask, int64_t N, int d,
+                                                          int64_t rpb, const float* __restrict__ mean,
+                                                          float* __restrict__ psc) {
+  __shared__ float red[2][4];
+  const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(N, r0 + rpb);
+  float l2 = 0.f, tv = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
+    if (m == 0.f) continue;
+    for (int c = threadIdx.x; c < d; c += 256) {
+      const float yy = ld(y, y_dtype, r * d + c);
+      const float e = yy - ld(yhat, yh_dtype, r * d + c);
+      const float dv = yy - mean[c];
+      l2 = fmaf(e, e, l2);
+      tv = fmaf(dv, dv, tv);
+    }
+  }
+  l2 = wave_sum(l2);
+  tv = wave_sum(tv);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][w] = l2;
+    red[1][w] = tv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    psc[2 * blockIdx.x + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    psc[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+template <typename GT>
+__global__ __launch_bounds__(256) void fvu_grad_kernel(const void* __restrict__ y, int y_dtype,
+                                                       const void* __restrict__ yhat, int yh_dtype,
+                                                       const uint8_t* __restrict__ mask, int64_t N, int d,
+                                                       const float* __restrict__ psc, int NB, float gscale,
+                                                       float* __restrict__ out_scalars, GT* __restrict__ G) {
+  // every block re-derives the totals in the same fixed order
+  float l2 = 0.f, tv = 0.f;
+  for (int b = 0; b < NB; ++b) {
+    l2 += psc[2 * b];
+    tv += psc[2 * b + 1];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out_scalars[0] = l2 / tv;
+    out_scalars[1] = l2;
+    out_scalars[2] = tv;
+  }
+  if (!G) return;
+  const float coef = -2.f * gscale / tv;
+  const int64_t total = N * (int64_t)d;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+    const int64_t r = i / d;  // d % 4 == 0: the 4 elements share a row
+    const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = coef * m * (ld(y, y_dtype, i + q) - ld(yhat, yh_dtype, i + q));
+    if constexpr (sizeof(GT) == 2) {
+      uint2 u;
+      u.x = pack_bf16x2(g[0], g[1]);
+      u.y = pack_bf16x2(g[2], g[3]);
+      *reinterpret_cast<uint2*>(G + i) = u;
+    } else {
+      *reinterpret_cast<float4*>(G + i) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+  }
+}
+
+}  // namespace clt
+
+using namespace clt;
+
+extern "C" size_t clt_fvu_workspace_bytes(int64_t N, int d) {
+  if (N <= 0 || d <= 0) return 256;
+  const size_t nb = (size_t)fvu_blocks(N);
+  return (nb * (size_t)d + nb + (size_t)d + 1 + 2 * nb + 16) * sizeof(float);
+}
+
+extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask,
+                               int64_t N, int d, float gscale, float* out_scalars, void* G, int g_dtype,
+                               void* workspace, size_t workspace_bytes, clt_stream_t stream) {
+  CLT_CHECK_ARG(y && yhat && out_scalars && workspace, "clt_fvu_fwd_bwd: null pointer");
+  CLT_CHECK_ARG(N > 0 && d > 0, "clt_fvu_fwd_bwd: bad sizes");
+  CLT_CHECK_ARG(valid_dtype(y_dtype) && valid_dtype(yhat_dtype) && (!G || valid_dtype(g_dtype)), "clt_fvu_fwd_bwd: bad dtype");
+  CLT_UNSUPPORTED(d % 4 == 0, "clt_fvu_fwd_bwd: d=%d must be a multiple of 4", d);
+  CLT_CHECK_ARG(!G || aligned16(G), "clt_fvu_fwd_bwd: G must be 16-byte aligned");
+  if (workspace_bytes < clt_fvu_workspace_bytes(N, d)) {
+    set_error("clt_fvu_fwd_bwd: workspace too small");
+    return CLT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int NB = fvu_blocks(N);
+  const int64_t rpb = (N + NB - 1) / NB;
+  float* ws = reinterpret_cast<float*>(workspace);
+  float* pcol = ws;
+  float* pcnt = pcol + (size_t)NB * d;
+  float* mean = pcnt + NB;
+  float* psc = mean + d + 1;
+  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
+  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
+                     d, mean);
+  hipLaunchKernelGGL(fvu_partial_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d, rpb,
+                     (const float*)mean, psc);
+  const int64_t total = N * (int64_t)d;
+  int64_t gb64 = (total + 1023) / 1024;
+  int gb = gb64 > 2048 ? 2048 : (int)gb64;
+  if (g_dtype == CLT_BF16)
+    hipLaunchKernelGGL((fvu_grad_kernel<bf16_t>), dim3(gb), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d,
+                       (const float*)psc, NB, gscale, out_scalars, (bf16_t*)G);
+  else
+    hipLaunchKernelGGL((fvu_grad_kernel<float>), dim3(gb), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d,
+                       (const float*)psc, NB, gscale, out_scalars, (float*)G);
+  CLT_CHECK_LAUNCH("clt_fvu_fwd_bwd");
+  return CLT_OK;
+}

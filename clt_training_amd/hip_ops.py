@@ -1,0 +1,216 @@
+"""Tensor-level wrappers over the C ABI: raw device pointers + shapes + the current HIP stream.
+
+PyTorch is used for device memory, streams and autograd plumbing only; every
+function here ends in a hand-written gfx950 kernel of libcltmi355.so and raises
+if the tensors are not on a GPU."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import CLT_BF16, CLT_DECODE_ACCUMULATE, CLT_DECODE_ROUND_ACTS, CLT_F32, check
+
+_DT = {torch.float32: CLT_F32, torch.bfloat16: CLT_BF16}
+
+
+def _dt(t: Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}: only float32 / bfloat16") from None
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t: Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("clt_training_amd ops need tensors on an MI355X GPU (there is no CPU fallback)")
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _idx(idx: Tensor) -> Tensor:
+    return _c(idx if idx.dtype == torch.int64 else idx.to(torch.int64))
+
+
+_ws_cache: dict = {}
+
+
+def workspace(device, nbytes: int, tag: str = "default") -> Tensor:
+    """Grow-only per-device scratch buffer (stream-ordered reuse on the current stream)."""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- encoder
+def encoder_gemm_relu(x: Tensor, W: Tensor, b: Optional[Tensor], out_dtype=None, out: Optional[Tensor] = None) -> Tensor:
+    x, W = _c(x), _c(W)
+    assert x.dtype == W.dtype and x.shape[1] == W.shape[1]
+    N, d = x.shape
+    M = W.shape[0]
+    out_dtype = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty(N, M, dtype=out_dtype, device=x.device)
+    b = None if b is None else _c(b)
+    check(_lib.load().clt_encoder_gemm_relu(_ptr(x), _ptr(W), _dt(x), _ptr(b), _dt(b) if b is not None else 0,
+                                            _ptr(out), _DT[out_dtype], N, M, d, _stream(x)), "clt_encoder_gemm_relu")
+    return out
+
+
+def topk_rows(vals: Tensor, k: int, cand_idx: Optional[Tensor] = None, counts: Optional[Tensor] = None,
+              out_dtype=None):
+    assert vals.dim() == 2 and vals.stride(1) == 1
+    N, L = vals.shape
+    ld = vals.stride(0) if N > 1 else L
+    out_dtype = out_dtype or vals.dtype
+    ov = torch.empty(N, k, dtype=out_dtype, device=vals.device)
+    oi = torch.empty(N, k, dtype=torch.int64, device=vals.device)
+    if cand_idx is not None:
+        cand_idx = _idx(cand_idx)
+        assert cand_idx.shape == vals.shape and vals.is_contiguous()
+    if counts is not None:
+        counts = _c(counts.to(torch.int32))
+    check(_lib.load().clt_topk_rows(_ptr(vals), _dt(vals), ld, _ptr(cand_idx), _ptr(counts), N, L, k, _ptr(ov),
+                                    _DT[out_dtype], _ptr(oi), _stream(vals)), "clt_topk_rows")
+    return ov, oi
+
+
+def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=None):
+    """relu(x W^T + b) -> row top-k (fused_encoder.py:310-322,372)."""
+    x, W = _c(x), _c(W)
+    assert x.dtype == W.dtype and x.shape[1] == W.shape[1]
+    N, d = x.shape
+    M = W.shape[0]
+    out_dtype = out_dtype or x.dtype
+    lib = _lib.load()
+    nbytes = lib.clt_encode_topk_workspace_bytes(N, M, _DT[out_dtype])
+    ws = workspace(x.device, nbytes, "pre")
+    ov = torch.empty(N, k, dtype=out_dtype, device=x.device)
+    oi = torch.empty(N, k, dtype=torch.int64, device=x.device)
+    b = None if b is None else _c(b)
+    check(lib.clt_encode_topk_fwd(_ptr(x), _ptr(W), _dt(x), _ptr(b), _dt(b) if b is not None else 0, N, M, d, k,
+                                  _ptr(ov), _DT[out_dtype], _ptr(oi), _ptr(ws), ws.numel(), _stream(x)),
+          "clt_encode_topk_fwd")
+    return ov, oi
+
+
+# ----------------------------------------------------------------------------- decoder
+def decode_fwd(idx: Tensor, v: Tensor, W: Tensor, *, post_enc: Optional[Tensor] = None,
+               post_scale: Optional[Tensor] = None, bias: Optional[Tensor] = None, out: Optional[Tensor] = None,
+               out_dtype=None, accumulate: bool = False, round_acts: bool = False, want_acts: bool = False):
+    idx, v, W = _idx(idx), _c(v), _c(W)
+    N, k = idx.shape
+    M, d = W.shape
+    out_dtype = out_dtype or W.dtype
+    if out is None:
+        assert not accumulate
+        out = torch.empty(N, d, dtype=out_dtype, device=W.device)
+    acts = torch.empty(N, k, dtype=torch.float32, device=W.device) if want_acts else None
+    flags = (CLT_DECODE_ACCUMULATE if accumulate else 0) | (CLT_DECODE_ROUND_ACTS if round_acts else 0)
+    for t in (post_enc, post_scale, bias):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    check(_lib.load().clt_decode_fwd(_ptr(idx), _ptr(v), _dt(v), _ptr(post_enc), _ptr(post_scale), _ptr(W), _dt(W), M, d,
+                                     _ptr(bias), _ptr(out), _dt(out), flags, _ptr(acts), N, k, _stream(W)),
+          "clt_decode_fwd")
+    return (out, acts) if want_acts else out
+
+
+def decode_bwd_acts(idx: Tensor, v: Tensor, W: Tensor, G: Tensor, *, post_enc: Optional[Tensor] = None,
+                    post_scale: Optional[Tensor] = None, grad_acts: Optional[Tensor] = None,
+                    want_e_post: bool = False):
+    idx, v, W, G = _idx(idx), _c(v), _c(W), _c(G)
+    N, k = idx.shape
+    M, d = W.shape
+    accumulate = grad_acts is not None
+    if grad_acts is None:
+        grad_acts = torch.empty(N, k, dtype=torch.float32, device=W.device)
+    e_post = torch.empty(N, k, dtype=torch.float32, device=W.device) if want_e_post else None
+    e_scale = torch.empty(N, k, dtype=torch.float32, device=W.device) if post_scale is not None else None
+    check(_lib.load().clt_decode_bwd_acts(_ptr(idx), _ptr(v), _dt(v), _ptr(post_enc), _ptr(post_scale), _ptr(W), _dt(W),
+                                          M, d, _ptr(G), _dt(G), _ptr(grad_acts), int(accumulate), _ptr(e_post),
+                                          _ptr(e_scale), N, k, _stream(W)), "clt_decode_bwd_acts")
+    return grad_acts, e_post, e_scale
+
+
+# ----------------------------------------------------------------------------- segments
+class Segments:
+    """Entries (token, slot) grouped by latent: built once per source layer, shared by
+    the decoder grad-W of every target and by the encoder backward."""
+
+    __slots__ = ("perm", "offsets", "M", "k")
+
+    def __init__(self, perm, offsets, M, k):
+        self.perm, self.offsets, self.M, self.k = perm, offsets, M, k
+
+
+def segments_build(idx: Tensor, M: int) -> Segments:
+    idx = _idx(idx)
+    n = idx.numel()
+    lib = _lib.load()
+    perm = torch.empty(n, dtype=torch.int32, device=idx.device)
+    offsets = torch.empty(M + 1, dtype=torch.int32, device=idx.device)
+    nbytes = lib.clt_segments_workspace_bytes(n, M)
+    ws = workspace(idx.device, nbytes, "seg")
+    check(lib.clt_segments_build(_ptr(idx), n, M, _ptr(perm), _ptr(offsets), _ptr(ws), ws.numel(), _stream(idx)),
+          "clt_segments_build")
+    return Segments(perm, offsets, M, idx.shape[-1])
+
+
+def spt_dense(seg: Segments, vals: Tensor, dense: Tensor, *, gate: Optional[Tensor] = None, out_dtype=None,
+              want_rowsum: bool = False, out: Optional[Tensor] = None):
+    vals, dense = _c(vals), _c(dense)
+    assert vals.dtype == torch.float32 and vals.numel() == seg.perm.numel()
+    d = dense.shape[1]
+    out_dtype = out_dtype or dense.dtype
+    if out is None:
+        out = torch.empty(seg.M, d, dtype=out_dtype, device=dense.device)
+    rowsum = torch.empty(seg.M, dtype=torch.float32, device=dense.device) if want_rowsum else None
+    gate = None if gate is None else _c(gate)
+    check(_lib.load().clt_spt_dense(_ptr(seg.perm), _ptr(seg.offsets), seg.M, _ptr(vals), _ptr(gate),
+                                    _dt(gate) if gate is not None else 0, _ptr(dense), _dt(dense), d, seg.k, _ptr(out),
+                                    _dt(out), _ptr(rowsum), _stream(dense)), "clt_spt_dense")
+    return (out, rowsum) if want_rowsum else out
+
+
+def segment_sum(seg: Segments, a: Tensor, b: Optional[Tensor] = None):
+    a = _c(a)
+    assert a.dtype == torch.float32
+    oa = torch.empty(seg.M, dtype=torch.float32, device=a.device)
+    ob = None
+    if b is not None:
+        b = _c(b)
+        ob = torch.empty(seg.M, dtype=torch.float32, device=a.device)
+    check(_lib.load().clt_segment_sum(_ptr(seg.perm), _ptr(seg.offsets), seg.M, _ptr(a), _ptr(oa), _ptr(b), _ptr(ob),
+                                      _stream(a)), "clt_segment_sum")
+    return oa, ob
+
+
+# ----------------------------------------------------------------------------- FVU
+def fvu_fwd_bwd(y: Tensor, yhat: Tensor, mask: Optional[Tensor], gscale: float = 1.0, want_grad: bool = True,
+                g_dtype=None):
+    """Returns (scalars[3] = fvu, l2, tv on device, G or None)."""
+    y, yhat = _c(y), _c(yhat)
+    N, d = y.shape
+    lib = _lib.load()
+    ws = workspace(y.device, lib.clt_fvu_workspace_bytes(N, d), "fvu")
+    sc = torch.empty(3, dtype=torch.float32, device=y.device)
+    g_dtype = g_dtype or yhat.dtype
+    G = torch.empty(N, d, dtype=g_dtype, device=y.device) if want_grad else None
+    if mask is not None:
+        mask = _c(mask.to(torch.bool)).view(torch.uint8)
+    check(lib.clt_fvu_fwd_bwd(_ptr(y), _dt(y), _ptr(yhat), _dt(yhat), _ptr(mask), N, d, float(gscale), _ptr(sc), _ptr(G),
+                              _DT[g_dtype], _ptr(ws), ws.numel(), _stream(y)), "clt_fvu_fwd_bwd")
+    return sc, G

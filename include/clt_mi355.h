@@ -1,0 +1,171 @@
+/*
+ * clt_mi355.h -- C ABI of libcltmi355.so: the MI355X (gfx950) implementation of the
+ * SAE / cross-layer-transcoder train-step hot path of EleutherAI/clt-training.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer unless its name starts with h_;
+ *   - every entry point returns 0 on success and a negative clt_status on
+ *     failure, never throws, never synchronises and never allocates: outputs
+ *     and workspaces are passed in by the caller (the reference's ops allocate
+ *     with torch.empty/zeros: kernels.py:81,244; xformers.py:56-58,208-211);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it;
+ *   - dtype codes: CLT_F32 = 0, CLT_BF16 = 1;
+ *   - indices at the seam are int64 exactly as torch.topk returns them
+ *     (fused_encoder.py:30, xformers.py:59); latent counts must be < 2^31;
+ *   - row-major, contiguous tensors; d (feature width) must be a multiple of
+ *     8 (bf16) or 4 (fp32) so that every row is a whole number of 16-byte chunks.
+ *
+ * Citations are file:line under /root/reference/.
+ */
+#ifndef CLT_MI355_H
+#define CLT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* clt_stream_t;
+
+enum clt_dtype { CLT_F32 = 0, CLT_BF16 = 1 };
+
+enum clt_status {
+  CLT_OK = 0,
+  CLT_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, misaligned pointer   */
+  CLT_ERR_UNSUPPORTED = -2,  /* shape / dtype outside what the kernels are built for  */
+  CLT_ERR_LAUNCH = -3,       /* hipGetLastError() after a launch was not hipSuccess   */
+  CLT_ERR_WORKSPACE = -4     /* workspace smaller than the *_workspace_bytes() answer */
+};
+
+/* Library version (major*10000 + minor*100 + patch) and last error text (thread local). */
+int clt_version(void);
+const char* clt_last_error(void);
+
+/* ------------------------------------------------------------------ encoder
+ * Replaces the no_grad body of sparsify.fused_encoder.fused_encoder
+ * (fused_encoder.py:310-312, nanogpt.py:321):  pre = relu(x @ W^T + b).
+ *   x [N,d], W [M,d] in `in_dtype` (bf16 -> bf16 MFMA, f32 -> exact f32 MFMA);
+ *   bias [M] in `bias_dtype` or NULL;  pre [N,M] in `out_dtype`, ld = M.
+ * fp32 accumulation, one rounding to out_dtype after the bias add.  */
+int clt_encoder_gemm_relu(const void* x, const void* W, int in_dtype, const void* bias, int bias_dtype,
+                          void* pre, int out_dtype, int64_t N, int64_t M, int d, clt_stream_t stream);
+
+/* Row top-k: replaces torch.topk(pre, k, dim=1, sorted=False) (fused_encoder.py:30,372)
+ * and, with cand_idx != NULL, the TP merge top-k + gather (fused_encoder.py:359-360).
+ *   vals [N,L] (leading dimension ld, `val_dtype`), values must be >= 0 (post-ReLU);
+ *   cand_idx [N,L] int64 or NULL (NULL: the column number is the index);
+ *   counts  [N] int32 or NULL: number of valid leading entries of each row (NULL: L);
+ *   out_vals [N,k] in `out_dtype`, out_idx [N,k] int64.
+ * Tie rule: larger value first, then LOWEST index.  Output order: value
+ * descending, index ascending.  With cand_idx == NULL zero entries are never
+ * candidates; a row with fewer than k positive entries is completed with
+ * (value 0, the lowest column numbers not yet selected) -- exactly what the
+ * tie rule gives for a post-ReLU row.  With cand_idx != NULL zeros are ordinary
+ * candidates and every row must hold at least k of them.   k <= 256.   */
+int clt_topk_rows(const void* vals, int val_dtype, int64_t ld, const int64_t* cand_idx, const int32_t* counts,
+                  int64_t N, int64_t L, int k, void* out_vals, int out_dtype, int64_t* out_idx,
+                  clt_stream_t stream);
+
+/* Fused convenience: encoder GEMM + bias + ReLU + row top-k (whole of
+ * fused_encoder.py:310-322,372 for activation="topk").  `workspace` holds the
+ * pre-activation matrix in out_dtype.  */
+size_t clt_encode_topk_workspace_bytes(int64_t N, int64_t M, int out_dtype);
+int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, const void* bias, int bias_dtype,
+                        int64_t N, int64_t M, int d, int k, void* out_vals, int out_dtype, int64_t* out_idx,
+                        void* workspace, size_t workspace_bytes, clt_stream_t stream);
+
+/* ------------------------------------------------------------------ decoder
+ * Replaces decoder_impl / xformers_embedding_bag forward (utils.py:442-457,
+ * xformers.py:15-90) with the post-encoder affine (sparse_coder.py:136-140) and the
+ * decoder bias add (sparse_coder.py:661) optionally fused:
+ *   a'[n,j] = (v[n,j] + post_enc[idx]*(v>0)) * post_scale[idx]      (either may be NULL)
+ *   out[n,:] = (flags & CLT_DECODE_ACCUMULATE ? out[n,:] : 0) + bias + sum_j a'[n,j] * W[idx[n,j],:]
+ * v [N,k] in `v_dtype`; W [M,d] in `w_dtype`; post_enc/post_scale/bias fp32;
+ * out [N,d] in `out_dtype`; acts_out [N,k] fp32 or NULL receives a'.  fp32 accumulation. */
+#define CLT_DECODE_ACCUMULATE 1 /* out += ... instead of out = ...                                   */
+#define CLT_DECODE_ROUND_ACTS 2 /* round a' to bf16 first: top_acts.to(self.dtype), sparse_coder.py:660 */
+int clt_decode_fwd(const int64_t* idx, const void* v, int v_dtype, const float* post_enc, const float* post_scale,
+                   const void* W, int w_dtype, int64_t M, int d, const float* bias, void* out, int out_dtype,
+                   int flags, float* acts_out, int64_t N, int k, clt_stream_t stream);
+
+/* Gradient w.r.t. the bag weights (xformers.py:167-171: g_acts[n,j] = G[n,:].W[idx[n,j],:])
+ * with the backward of the post-encoder affine fused (autograd of sparse_coder.py:136-140):
+ *   ga = G[n,:] . W[idx,:];  u = ga * post_scale[idx]
+ *   grad_acts[n,j]  (+)= u                       (accumulate_grad_acts: CLT leaf grad, sparse_coder.py:72-76)
+ *   e_post[n,j]  = u * (v>0)                     (NULL if post_enc grads are not needed)
+ *   e_scale[n,j] = ga * (v + post_enc[idx]*(v>0))  (NULL unless post_scale is given)
+ * G [N,d] in `g_dtype`; grad_acts/e_post/e_scale fp32 [N,k].                               */
+int clt_decode_bwd_acts(const int64_t* idx, const void* v, int v_dtype, const float* post_enc,
+                        const float* post_scale, const void* W, int w_dtype, int64_t M, int d, const void* G,
+                        int g_dtype, float* grad_acts, int accumulate_grad_acts, float* e_post, float* e_scale,
+                        int64_t N, int k, clt_stream_t stream);
+
+/* ------------------------------------------------------------------ segments
+ * Stable sort of the N*k (token, slot) entries by latent: replaces the COO sort of
+ * kernels.py:42-51 and the count/cumsum/reverse-map kernels of xformers.py:93-122,
+ * deterministically (entries of one latent stay in ascending entry id).
+ *   perm [N*k] int32: entry ids (n*k + j) grouped by latent; offsets [M+1] int32.  */
+size_t clt_segments_workspace_bytes(int64_t n_entries, int64_t M);
+int clt_segments_build(const int64_t* idx, int64_t n_entries, int64_t M, int32_t* perm, int32_t* offsets,
+                       void* workspace, size_t workspace_bytes, clt_stream_t stream);
+
+/* sparse^T @ dense over prebuilt segments: replaces triton_sparse_transpose_dense_matmul
+ * (kernels.py:14-54,113-216: encoder grad-W, fused_encoder.py:150-155) and
+ * aggregate_gradient_for_embedding_k (xformers.py:125-176: decoder grad-W):
+ *   out[r,:] = sum_{e in segment r} vals[e] * dense[e / k, :]     (every row written, zeros if empty)
+ *   rowsum[r] = sum_{e in segment r} vals[e] * (mask ? mask_vals[e] > 0 : 1)   (NULL to skip; this is
+ *               grad_b of fused_encoder.py:140-143)
+ * vals [N*k] fp32; vals_gate [N*k] (`gate_dtype`) or NULL: when given, vals[e] is multiplied by
+ * (vals_gate[e] > 0) -- the (values > 0) mask of fused_encoder.py:97; dense [N,d] `dense_dtype`;
+ * out [M,d] `out_dtype`.  Atomic-free and bitwise reproducible.                                 */
+int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_t M, const float* vals, const void* vals_gate,
+                  int gate_dtype, const void* dense, int dense_dtype, int d, int k, void* out, int out_dtype,
+                  float* rowsum, clt_stream_t stream);
+
+/* Per-latent sums of up to two per-entry arrays (post_enc / post_enc_scale grads: the
+ * scatter-adds autograd generates for sparse_coder.py:136-140):
+ *   out_a[r] = sum_{e in segment r} a[e];  out_b likewise (b/out_b may be NULL).  fp32.  */
+int clt_segment_sum(const int32_t* perm, const int32_t* offsets, int64_t M, const float* a, float* out_a,
+                    const float* b, float* out_b, clt_stream_t stream);
+
+/* ------------------------------------------------------------------ FVU
+ * Replaces sparse_coder.py:207-221.
+ *   stats(y, mask): colsum[d] = sum_n m*y, count = sum m, then tv = sum m (y - colsum/count)^2.
+ *   loss(y, yhat, mask): l2 = sum (m (y - yhat))^2, fvu = l2 / tv, and
+ *   G[n,:] = gscale * (-2 / tv) * m (y - yhat)  in `g_dtype`  (d fvu / d yhat times gscale).
+ * mask [N] uint8 (torch.bool) or NULL.  scalars (device, fp32): out[0] = fvu, out[1] = l2, out[2] = tv.
+ * workspace: clt_fvu_workspace_bytes(N, d).                                                   */
+size_t clt_fvu_workspace_bytes(int64_t N, int d);
+int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask, int64_t N,
+                    int d, float gscale, float* out_scalars, void* G, int g_dtype, void* workspace,
+                    size_t workspace_bytes, clt_stream_t stream);
+
+/* ------------------------------------------------------------------ Adam
+ * torch.optim.Adam defaults (trainer.py:178-186: betas=(b1,b2), eps 1e-8, no weight decay,
+ * no amsgrad) over a table of tensors in ONE launch.
+ * Each clt_adam_tensor describes one parameter; `tensors` is a DEVICE array of n_tensors of
+ * them; `chunk_tensor`/`chunk_start` are DEVICE arrays of n_chunks int32/int64 mapping each
+ * workgroup to (tensor id, first element).  lr may differ per tensor (trainer.py:166-173); the
+ * effective rate is tensor.lr * lr_factor (the LambdaLR factor of trainer.py:45-58).
+ * Math in fp32, one rounding per stored value.  step is 1-based.                            */
+typedef struct clt_adam_tensor {
+  void* p;
+  const void* g;
+  void* m;
+  void* v;
+  int64_t numel;
+  float lr;
+  int32_t p_dtype; /* dtype of p, m and v */
+  int32_t g_dtype;
+  int32_t pad_;
+} clt_adam_tensor;
+int clt_adam_step(const clt_adam_tensor* tensors, int n_tensors, const int32_t* chunk_tensor,
+                  const int64_t* chunk_start, int64_t n_chunks, int chunk_elems, float lr_factor, float b1,
+                  float b2, float eps, int step, clt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLT_MI355_H */

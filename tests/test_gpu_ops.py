@@ -1,0 +1,244 @@
+"""GPU parity tests of the raw C-ABI entry points against the CPU oracle.
+Run on an MI355X:  python -m pytest tests -m gpu"""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import clt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+FP32 = dict(rtol=1e-5, atol=1e-6)   # BASELINE.json tolerance, fp32
+BF16 = dict(rtol=1e-2, atol=1e-2)   # BASELINE.json tolerance, bf16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from clt_training_amd import hip_ops
+    assert torch.cuda.is_available()
+    return hip_ops
+
+
+def canon(vals, idx):
+    return O.topk_merge(vals.float().cpu(), idx.cpu(), vals.shape[1])
+
+
+# --------------------------------------------------------------------------- decode
+@pytest.mark.parametrize("name", ["decoder_d48", "decoder_d64", "decoder_c"])
+def test_decode_golden(ops, name):
+    t, meta = load_golden(name)
+    idx, acts, W, G = (t[k].to(DEV) for k in ("idx", "acts", "W", "G"))
+    y = ops.decode_fwd(idx, acts, W)
+    torch.testing.assert_close(y.cpu(), t["y"], **FP32)
+    ga, _, _ = ops.decode_bwd_acts(idx, acts, W, G)
+    torch.testing.assert_close(ga.cpu(), t["gacts"], **FP32)
+    seg = ops.segments_build(idx, meta["M"])
+    order, offsets = O.segments_build(t["idx"], meta["M"])
+    assert torch.equal(seg.perm.cpu().long(), order)
+    assert torch.equal(seg.offsets.cpu().long(), offsets)
+    gW = ops.spt_dense(seg, acts.float(), G)
+    torch.testing.assert_close(gW.cpu(), t["gW"], **FP32)
+    torch.testing.assert_close(gW.cpu(), t["spT"], **FP32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,d,M,k", [(257, 768, 4096, 32), (64, 2048, 1024, 64), (33, 4096, 512, 192), (19, 104, 300, 70)])
+def test_decode_fused_random(ops, dtype, N, d, M, k):
+    g = torch.Generator().manual_seed(N + d)
+    W = (torch.randn(M, d, generator=g) / math.sqrt(d)).to(dtype)
+    v = torch.rand(N, k, generator=g)
+    v[:, ::5] = 0.0
+    idx = torch.stack([torch.randperm(M, generator=g)[:k] for _ in range(N)])
+    pe = 0.1 * torch.randn(M, generator=g)
+    ps = 1 + 0.1 * torch.randn(M, generator=g)
+    bias = torch.randn(d, generator=g)
+    G = torch.randn(N, d, generator=g).to(dtype)
+    tol = FP32 if dtype == torch.float32 else BF16
+    a = O.post_affine_fwd(v, idx, pe, ps)
+    y_ref = O.decode_fwd(idx, a, W.float()) + bias
+    y, acts = ops.decode_fwd(idx.to(DEV), v.to(DEV), W.to(DEV), post_enc=pe.to(DEV), post_scale=ps.to(DEV),
+                             bias=bias.to(DEV), want_acts=True)
+    assert y.dtype == dtype
+    torch.testing.assert_close(acts.cpu(), a, **FP32)
+    torch.testing.assert_close(y.float().cpu(), y_ref, **tol)
+    # accumulate
+    y2 = ops.decode_fwd(idx.to(DEV), v.to(DEV), W.to(DEV), post_enc=pe.to(DEV), post_scale=ps.to(DEV),
+                        out=y.clone(), accumulate=True)
+    torch.testing.assert_close(y2.float().cpu(), 2 * y_ref - bias, **tol)
+    # backward wrt acts + affine
+    gW_ref, ga_ref = O.decode_bwd(idx, a, W.float(), G.float())
+    u_ref, gp_ref, gs_ref = O.post_affine_bwd(v, idx, pe, ps, ga_ref)
+    acc0 = torch.randn(N, k, generator=g)
+    gacc, e_post, e_scale = ops.decode_bwd_acts(idx.to(DEV), v.to(DEV), W.to(DEV), G.to(DEV), post_enc=pe.to(DEV),
+                                                post_scale=ps.to(DEV), grad_acts=acc0.to(DEV), want_e_post=True)
+    torch.testing.assert_close(gacc.cpu(), acc0 + u_ref, rtol=1e-4, atol=1e-4)
+    seg = ops.segments_build(idx.to(DEV), M)
+    gp, gs = ops.segment_sum(seg, e_post, e_scale)
+    torch.testing.assert_close(gp.cpu(), gp_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gs.cpu(), gs_ref, rtol=1e-4, atol=1e-4)
+    gW, rs = ops.spt_dense(seg, acts, G.to(DEV), want_rowsum=True)
+    assert gW.dtype == dtype
+    torch.testing.assert_close(gW.float().cpu(), gW_ref, **tol)
+    rs_ref = torch.zeros(M).index_add_(0, idx.reshape(-1), a.reshape(-1))
+    torch.testing.assert_close(rs.cpu(), rs_ref, rtol=1e-4, atol=1e-5)
+
+
+def test_segments_skewed(ops):
+    """One latent active on every token (long segment) + many empty latents."""
+    N, k, M, d = 700, 8, 512, 64
+    g = torch.Generator().manual_seed(5)
+    idx = torch.stack([torch.cat([torch.tensor([7]), 8 + torch.randperm(M - 8, generator=g)[: k - 1]]) for _ in range(N)])
+    vals = torch.randn(N, k, generator=g)
+    dense = torch.randn(N, d, generator=g)
+    seg = ops.segments_build(idx.to(DEV), M)
+    order, offsets = O.segments_build(idx, M)
+    assert torch.equal(seg.perm.cpu().long(), order) and torch.equal(seg.offsets.cpu().long(), offsets)
+    out = ops.spt_dense(seg, vals.to(DEV), dense.to(DEV))
+    torch.testing.assert_close(out.cpu(), O.sparse_transpose_dense_matmul(idx, vals, dense, M), rtol=1e-4, atol=1e-4)
+    gate = torch.randn(N, k, generator=g)
+    out2, rs = ops.spt_dense(seg, vals.to(DEV), dense.to(DEV), gate=gate.to(DEV), want_rowsum=True)
+    vg = vals * (gate > 0)
+    torch.testing.assert_close(out2.cpu(), O.sparse_transpose_dense_matmul(idx, vg, dense, M), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rs.cpu(), torch.zeros(M).index_add_(0, idx.reshape(-1), vg.reshape(-1)), rtol=1e-4, atol=1e-4)
+
+
+# --------------------------------------------------------------------------- top-k
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,L,k", [(37, 512, 32), (5, 98304, 32), (9, 24576, 64), (6, 16384, 192), (11, 8200, 100),
+                                   (16, 130, 7), (3, 4096, 256)])
+def test_topk_rows_bit_exact(ops, dtype, N, L, k):
+    g = torch.Generator().manual_seed(L + k)
+    pre = torch.relu(torch.randn(N, L, generator=g)).to(dtype)  # bf16 rounding creates many ties
+    if dtype == torch.float32:
+        pre = (pre * 8).round() / 8  # force ties in fp32 too
+    v_ref, i_ref = O.topk_lowest_index(pre.float(), k)
+    v, i = ops.topk_rows(pre.to(DEV), k)
+    assert torch.equal(i.cpu(), i_ref)          # bit-exact, already in canonical order
+    assert torch.equal(v.float().cpu(), v_ref)
+
+
+def test_topk_short_rows_fill_rule(ops):
+    """Rows with fewer than k positives are completed with the lowest unselected columns (value 0)."""
+    N, L, k = 8, 4096, 32
+    pre = torch.zeros(N, L)
+    pre[0, [5, 0, 4000]] = torch.tensor([3.0, 1.0, 2.0])
+    pre[1, :] = 0
+    pre[2, 10:30] = 1.0
+    pre[3, 100:200] = torch.arange(100, 0, -1).float()
+    pre[4, L - 1] = 9.0
+    pre[5, 0:31] = 2.0
+    pre[6, 1:40:2] = 5.0
+    v_ref, i_ref = O.topk_lowest_index(pre, k)
+    for dt in (torch.float32, torch.bfloat16):
+        v, i = ops.topk_rows(pre.to(dt).to(DEV), k)
+        assert torch.equal(i.cpu(), i_ref)
+        assert torch.equal(v.float().cpu(), v_ref)
+
+
+def test_topk_merge_explicit(ops):
+    """TP merge (fused_encoder.py:359-360): candidates [N, k*tp] with global indices, zeros allowed."""
+    N, k, tp = 50, 32, 4
+    g = torch.Generator().manual_seed(3)
+    vals = torch.relu(torch.randn(N, k * tp, generator=g)).to(torch.bfloat16)
+    idx = torch.stack([torch.randperm(100000, generator=g)[: k * tp] for _ in range(N)])
+    v_ref, i_ref = O.topk_merge(vals.float(), idx, k)
+    v, i = ops.topk_rows(vals.to(DEV), k, cand_idx=idx.to(DEV))
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(v.float().cpu(), v_ref)
+    counts = torch.randint(k, k * tp + 1, (N,), generator=g)
+    v_ref2, i_ref2 = [], []
+    for n in range(N):
+        a, b = O.topk_merge(vals[n : n + 1, : counts[n]].float(), idx[n : n + 1, : counts[n]], k)
+        v_ref2.append(a); i_ref2.append(b)
+    v, i = ops.topk_rows(vals.to(DEV), k, cand_idx=idx.to(DEV), counts=counts.to(DEV))
+    assert torch.equal(i.cpu(), torch.cat(i_ref2)) and torch.equal(v.float().cpu(), torch.cat(v_ref2))
+
+
+# --------------------------------------------------------------------------- encoder
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,M,d", [(128, 128, 64), (300, 520, 768), (77, 1000, 48), (1024, 4096, 256)])
+def test_encoder_gemm_exact_integers(ops, dtype, N, M, d):
+    """Small-integer operands: every product and partial sum is exact in fp32, so the MFMA
+    result must equal the oracle bit for bit whatever the accumulation order."""
+    g = torch.Generator().manual_seed(N + M + d)
+    x = torch.randint(-3, 4, (N, d), generator=g).float()
+    W = torch.randint(-3, 4, (M, d), generator=g).float()
+    b = torch.randint(-5, 6, (M,), generator=g).float()
+    ref = O.encoder_preacts(x, W, b, None)
+    pre = ops.encoder_gemm_relu(x.to(dtype).to(DEV), W.to(dtype).to(DEV), b.to(DEV), out_dtype=torch.float32)
+    assert torch.equal(pre.cpu(), ref)
+    if dtype == torch.bfloat16:
+        pre16 = ops.encoder_gemm_relu(x.to(dtype).to(DEV), W.to(dtype).to(DEV), b.to(dtype).to(DEV))
+        assert torch.equal(pre16.cpu(), ref.to(torch.bfloat16))
+        v, i = ops.encode_topk(x.to(dtype).to(DEV), W.to(dtype).to(DEV), b.to(DEV), 32)
+        v_ref, i_ref = O.topk_lowest_index(ref.to(torch.bfloat16).float(), 32)
+        assert torch.equal(i.cpu(), i_ref) and torch.equal(v.float().cpu(), v_ref)
+
+
+@pytest.mark.parametrize("name", ["encoder_a", "encoder_b"])
+def test_encoder_golden_fp32(ops, name):
+    t, meta = load_golden(name)
+    v, i = ops.encode_topk(t["x"].to(DEV), t["W"].to(DEV), t["b"].to(DEV), meta["k"])
+    assert torch.equal(i.cpu(), t["idx"])
+    torch.testing.assert_close(v.cpu(), t["vals"], **FP32)
+
+
+def test_encoder_gemm_random(ops):
+    g = torch.Generator().manual_seed(0)
+    N, M, d = 512, 2048, 768
+    x = torch.randn(N, d, generator=g)
+    W = torch.randn(M, d, generator=g) / math.sqrt(d)
+    b = 0.1 * torch.randn(M, generator=g)
+    ref = O.encoder_preacts(x, W, b, None)
+    pre = ops.encoder_gemm_relu(x.to(DEV), W.to(DEV), b.to(DEV))
+    torch.testing.assert_close(pre.cpu(), ref, rtol=1e-5, atol=1e-5)  # atol of tests/test_encode.py (assert_close default)
+    xb, Wb = x.to(torch.bfloat16), W.to(torch.bfloat16)
+    ref16 = O.encoder_preacts(xb.float(), Wb.float(), b, torch.bfloat16)
+    pre16 = ops.encoder_gemm_relu(xb.to(DEV), Wb.to(DEV), b.to(DEV))
+    torch.testing.assert_close(pre16.float().cpu(), ref16, **BF16)
+
+
+# --------------------------------------------------------------------------- FVU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("masked", [False, True])
+def test_fvu(ops, dtype, masked):
+    g = torch.Generator().manual_seed(1)
+    N, d = 1000, 768
+    y = (torch.randn(N, d, generator=g) + 0.3).to(dtype)
+    yhat = (y.float() + 0.5 * torch.randn(N, d, generator=g)).to(dtype)
+    mask = None
+    if masked:
+        mask = torch.ones(N, dtype=torch.bool)
+        mask[::128] = False
+    fvu, e, tv = O.fvu_fwd(y.float(), yhat.float(), mask)
+    G_ref = O.fvu_bwd(e, tv, mask, 0.5).float()
+    sc, G = ops.fvu_fwd_bwd(y.to(DEV), yhat.to(DEV), None if mask is None else mask.to(DEV), gscale=0.5)
+    torch.testing.assert_close(sc[0].cpu(), fvu.float(), rtol=1e-4, atol=1e-6)
+    tol = dict(rtol=1e-4, atol=1e-9) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-8)
+    torch.testing.assert_close(G.float().cpu(), G_ref, **tol)
+
+
+# --------------------------------------------------------------------------- Adam
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adam(dtype):
+    from clt_training_amd.adam import Adam
+    g = torch.Generator().manual_seed(2)
+    shapes = [(1000, 96), (77,), (3, 5), (70000,)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(dtype).to(DEV)) for s in shapes]
+    ref = [(p.detach().float().cpu().double(), torch.zeros(s).double(), torch.zeros(s).double()) for p, s in zip(ps, shapes)]
+    opt = Adam([dict(params=ps[:2], lr=torch.tensor(1e-2)), dict(params=ps[2:], lr=3e-3)], betas=(0.9, 0.999))
+    lrs = [1e-2, 1e-2, 3e-3, 3e-3]
+    for step in range(1, 4):
+        for i, p in enumerate(ps):
+            gr = torch.randn(shapes[i], generator=g).to(dtype)
+            p.grad = gr.to(DEV)
+            pp, m, v = ref[i]
+            ref[i] = O.adam_step(pp, gr.float(), m, v, step, lrs[i])
+            if dtype == torch.bfloat16:  # states are stored in bf16 between steps
+                ref[i] = tuple(O.round_to(t.float(), torch.bfloat16).double() for t in ref[i])
+        opt.step()
+        for i, p in enumerate(ps):
+            tol = FP32 if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+            torch.testing.assert_close(p.detach().float().cpu(), ref[i][0].float(), **tol)
