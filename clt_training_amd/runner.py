@@ -1,0 +1,92 @@
+"""CrossLayerRunner: mirror of sparsify/runner.py:11-201 for the coalescing modes on the
+hot path -- ``coalesce_topk="none"`` (every live source layer decodes into the current
+target with its own W_decs[j - i], runner.py:60-71) and ``"concat"`` with
+``topk_coalesced=False`` (per-target tied decoder over the concatenated candidates,
+runner.py:93-127).  Same bookkeeping: insertion-ordered live sources, deferred encoder
+backward (``restore``) for the sources that just wrote their last target."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .sparse_coder import MidDecoder, SparseCoder
+
+
+class CrossLayerRunner(object):
+    def __init__(self):
+        self.outputs = {}
+        self.to_restore = {}
+
+    def encode(self, x: Tensor, sparse_coder: SparseCoder, **kwargs):
+        return sparse_coder(x=x, y=None, return_mid_decoder=True, **kwargs)
+
+    def decode(self, mid_out: MidDecoder, y: Tensor, module_name: str, detach_grad: bool = False,
+               advance: bool = True, **kwargs):
+        cfg = mid_out.sparse_coder.cfg
+        if cfg.secondary_target_tied or cfg.coalesce_topk in ("per-layer", "group") or (
+                cfg.do_coalesce_topk and cfg.topk_coalesced):
+            raise NotImplementedError("only coalesce_topk in {'none', 'concat'} with topk_coalesced=False "
+                                      "is on the MI355X hot path")
+        self.outputs[module_name] = mid_out
+
+        candidate_indices, candidate_values, layer_mids = [], [], []
+        output = 0
+        to_delete = set()
+        out, hookpoint = None, None
+        for i, (hookpoint, layer_mid) in enumerate(self.outputs.items()):
+            if detach_grad:
+                layer_mid.detach()
+            divide_by = max(1, len(self.outputs) - 1) if layer_mid.sparse_coder.cfg.divide_cross_layer else 1
+            layer_mids.append(layer_mid)
+            if cfg.do_coalesce_topk:
+                # (idx + i*M) % M == idx (runner.py:53,122): the offset only matters to per-layer mode
+                candidate_indices.append(layer_mid.latent_indices)
+                candidate_values.append(layer_mid.current_latent_acts)
+            if detach_grad and advance:
+                self.to_restore[hookpoint] = (layer_mid, layer_mid.will_be_last)
+            if layer_mid.will_be_last:
+                to_delete.add(hookpoint)
+            if not cfg.do_coalesce_topk:
+                out = layer_mid(
+                    y,
+                    addition=(0 if hookpoint != module_name else (output / divide_by)),
+                    no_extras=(hookpoint != module_name),
+                    denormalize=(hookpoint == module_name),
+                    **kwargs,
+                )
+                if hookpoint != module_name:
+                    output = output + out.sae_out
+            else:
+                layer_mid.next()
+
+        if cfg.do_coalesce_topk:  # "concat", topk_coalesced=False (runner.py:118-127)
+            best_indices = torch.cat(candidate_indices, dim=1)
+            best_values = torch.cat(candidate_values, dim=1)
+            new_mid_out = mid_out.copy(indices=best_indices, activations=best_values)
+            out = new_mid_out(y, index=0, add_post_enc=False, **kwargs)
+            if advance:
+                del mid_out.x
+
+        assert hookpoint == module_name  # last output guaranteed to be the current layer
+        if not advance:
+            for layer_mid in layer_mids:
+                layer_mid.prev()
+        if advance:
+            for hookpoint in to_delete:
+                del self.outputs[hookpoint]
+        return out
+
+    def __call__(self, x: Tensor, y: Tensor, sparse_coder: SparseCoder, module_name: str, detach_grad: bool = False,
+                 dead_mask=None, loss_mask=None, *, encoder_kwargs: dict = {}, decoder_kwargs: dict = {}):
+        mid_out = self.encode(x, sparse_coder, dead_mask=dead_mask, **encoder_kwargs)
+        return self.decode(mid_out, y, module_name, detach_grad, loss_mask=loss_mask, **decoder_kwargs)
+
+    def restore(self):
+        for restorable, was_last in self.to_restore.values():
+            if was_last:
+                restorable.restore(True)
+        self.to_restore.clear()
+
+    def reset(self):
+        self.outputs.clear()
+        self.to_restore.clear()

@@ -1,0 +1,187 @@
+"""Trainer over cached activations: the train-step hot path of sparsify/trainer.py.
+
+The reference's ``Trainer`` (trainer.py:61-997) hooks a frozen HF model; everything
+between the hook and the optimizer step is reproduced here -- SAE construction rule
+(:113-146), Adam parameter groups + LR rule (:166-193), ``WarmupLinearSchedule`` (:45-58),
+step-0 data-dependent init (:547-592), the encode/decode/backward/restore order of the hook
+(:598-682), optimizer/scheduler order (:791-802) and fired-latent bookkeeping
+(:622-628, 806-816) -- with the model forward replaced by an iterator of cached activations
+``{hookpoint: (inputs[N, d], outputs[N, d])}`` (BASELINE.json north_star)."""
+from __future__ import annotations
+
+from dataclasses import replace
+from typing import Callable, Iterable, Optional
+
+import torch
+from torch import Tensor
+
+from .adam import Adam
+from .config import TrainConfig
+from .runner import CrossLayerRunner
+from .sparse_coder import SparseCoder
+
+
+class WarmupLinearSchedule(torch.optim.lr_scheduler.LambdaLR):
+    """trainer.py:45-58."""
+
+    def __init__(self, optimizer, warmup_steps, num_training_steps):
+        self.warmup_steps = warmup_steps
+        self.num_training_steps = num_training_steps
+        super().__init__(optimizer, self.lr_lambda, last_epoch=-1)
+
+    def lr_lambda(self, current_step):
+        if current_step < self.warmup_steps:
+            return float(current_step) / float(max(1, self.warmup_steps))
+        return max(0.0, float(self.num_training_steps - current_step)
+                   / float(max(1, self.num_training_steps - self.warmup_steps)))
+
+
+class Trainer:
+    """``Trainer(cfg, dataset, model=None, mesh=None)``.
+
+    ``cfg.hookpoints`` names the layers in network order; ``dataset`` is a sized iterable of
+    steps, each a dict ``hookpoint -> (inputs, outputs)`` of cached activations already on
+    the GPU (and optionally ``"loss_mask" -> bool[N]``); ``input_widths`` maps hookpoints to
+    d_model (inferred from the first batch when omitted)."""
+
+    def __init__(self, cfg: TrainConfig, dataset, model=None, mesh=None, *, device="cuda",
+                 input_widths: Optional[dict] = None, num_batches: Optional[int] = None):
+        if mesh is not None:
+            raise NotImplementedError("use clt_training_amd.tp for latent sharding over RCCL")
+        assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
+        if cfg.optimizer != "adam":
+            raise NotImplementedError("only optimizer='adam' is on the MI355X hot path")
+        if cfg.loss_fn != "fvu":
+            raise NotImplementedError("only loss_fn='fvu' is on the MI355X hot path")
+        cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
+        self.cfg = cfg
+        self.dataset = dataset
+        self.model = model
+        self.mesh = None
+        self.device = torch.device(device)
+        if input_widths is None:
+            first = next(iter(dataset))
+            input_widths = {h: first[h][0].shape[-1] for h in cfg.hookpoints}
+
+        # ---- SAE construction (trainer.py:113-146)
+        self.saes = {}
+        sources = []
+        for position, hook in enumerate(cfg.hookpoints):
+            for seed in cfg.init_seeds:
+                torch.manual_seed(seed)
+                name = f"{hook}/seed{seed}" if len(cfg.init_seeds) > 1 else hook
+                if cfg.cross_layer > 0:
+                    n_targets = min(cfg.cross_layer, len(cfg.hookpoints) - position)
+                    sources.append(position + n_targets)
+                    while sources[0] < position:
+                        sources.pop(0)
+                    n_sources = len(sources)
+                else:
+                    n_targets = n_sources = 0
+                sae_cfg = replace(cfg.sae, n_targets=n_targets, n_sources=n_sources)
+                self.saes[name] = SparseCoder(input_widths[hook], sae_cfg, self.device, dtype=torch.float32)
+
+        if num_batches is None:
+            num_batches = len(dataset)
+        # ---- optimizer (trainer.py:166-193)
+        pgs = [dict(params=list(sae.parameters()),
+                    lr=torch.tensor(cfg.lr or 2e-4 / (sae.num_latents / (2**14)) ** 0.5))
+               for sae in self.saes.values()]
+        adam = Adam(pgs, betas=(cfg.b1, cfg.b2))
+        self.optimizers = [adam]
+        self.lr_schedulers = [WarmupLinearSchedule(adam, cfg.lr_warmup_steps, num_batches)]
+
+        self.global_step = 0
+        self.num_tokens_since_fired = {
+            name: torch.zeros(sae.num_latents, device=self.device, dtype=torch.long) for name, sae in self.saes.items()}
+        self.did_fire = {name: torch.zeros(sae.num_latents, device=self.device, dtype=torch.bool)
+                         for name, sae in self.saes.items()}
+        self.runner = CrossLayerRunner()
+        self.last_fvu = {}
+        self.num_tokens_in_step = 0
+
+    # ------------------------------------------------------------------ step-0 init (trainer.py:547-592)
+    @torch.no_grad()
+    def _first_step_init(self, raw: SparseCoder, inputs: Tensor, outputs: Tensor):
+        if self.cfg.sae.transcode:
+            mean = -inputs.float().mean(0).to(raw.dtype)
+            raw.encoder.bias.data[:] = torch.nn.functional.linear(mean, raw.encoder.weight.data)
+        mean = outputs.float().mean(0)
+        if not hasattr(raw, "b_decs"):
+            raw.b_dec.data[:] = mean.to(raw.b_dec.dtype)
+        else:
+            raw.b_decs[0].data[:] = mean.to(raw.b_decs[0].dtype)
+        if raw.cfg.normalize_io:
+            in_norm = inputs.float().norm(dim=-1).mean()
+            out_norm = outputs.float().norm(dim=-1).mean()
+            raw.in_norm.data[:] = in_norm
+            raw.out_norm.data[:] = out_norm
+            for b_dec in raw.b_decs if hasattr(raw, "b_decs") else [raw.b_dec]:
+                b_dec.data[:] = b_dec.data * ((b_dec.shape[-1] ** 0.5) / out_norm)
+            raw.encoder.bias.data[:] = raw.encoder.bias.data * ((raw.encoder.weight.shape[-1] ** 0.5) / in_norm)
+
+    # ------------------------------------------------------------------ the hook body (trainer.py:492-682)
+    def hook(self, name: str, inputs: Tensor, outputs: Tensor, loss_mask: Optional[Tensor], acc_steps: int):
+        raw = self.saes[name]
+        if not self.cfg.sae.transcode:
+            inputs = outputs
+        if self.global_step == 0 and not self.cfg.finetune:
+            self._first_step_init(raw, inputs, outputs)
+        if raw.cfg.normalize_decoder and not self.cfg.sae.transcode:
+            raw.set_decoder_norm_to_unit_norm()
+        encoding = self.runner.encode(
+            inputs, sparse_coder=raw,
+            dead_mask=self.num_tokens_since_fired[name] > self.cfg.dead_feature_threshold)
+        out = self.runner.decode(encoding, outputs, module_name=name, detach_grad=True, loss_mask=loss_mask)
+        self.did_fire[name][encoding.latent_indices.flatten()] = True
+        self.last_fvu[name] = out.fvu.detach()
+        loss = out.fvu / acc_steps
+        loss.backward()
+        del loss
+        self.runner.restore()
+
+    def step(self, batch: dict):
+        """One pass over all hookpoints in network order + optimizer step (trainer.py:684-816)."""
+        acc_steps = self.cfg.grad_acc_steps * self.cfg.micro_acc_steps
+        self.runner.reset()
+        loss_mask = batch.get("loss_mask")
+        n_tok = 0
+        for name in self.cfg.hookpoints:
+            x, y = batch[name]
+            n_tok = x.shape[0]
+            self.hook(name, x, y, loss_mask, acc_steps)
+        self.num_tokens_in_step += n_tok
+        step, substep = divmod(self.global_step + 1, self.cfg.grad_acc_steps)
+        if substep == 0:
+            if self.cfg.sae.normalize_decoder and not self.cfg.sae.transcode:
+                for sae in self.saes.values():
+                    sae.remove_gradient_parallel_to_decoder_directions()
+            for optimizer in self.optimizers:
+                optimizer.step()
+                optimizer.zero_grad()
+            for scheduler in self.lr_schedulers:
+                scheduler.step()
+            with torch.no_grad():
+                for name, counts in self.num_tokens_since_fired.items():
+                    counts += self.num_tokens_in_step
+                    counts[self.did_fire[name]] = 0
+                self.num_tokens_in_step = 0
+                for mask in self.did_fire.values():
+                    mask.zero_()
+        self.global_step += 1
+        return self.last_fvu
+
+    def fit(self, log: Optional[Callable[[int, dict], None]] = None):
+        torch.set_float32_matmul_precision("high")  # trainer.py:378
+        for batch in self.dataset:
+            fvus = self.step(batch)
+            if log is not None:
+                log(self.global_step, fvus)
+        return self
+
+    def save(self, path):
+        for name, sae in self.saes.items():
+            sae.save_to_disk(f"{path}/{name}")
+
+
+SaeTrainer = Trainer

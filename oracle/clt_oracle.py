@@ -71,6 +71,15 @@ def encoder_forward(x, W, b, k, out_dtype=None):
     return topk_lowest_index(pre, k)
 
 
+def topk_selection_slack(pre: Tensor, idx: Tensor) -> Tensor:
+    """How far a selection is from an exact top-k of ``pre``: per row,
+    max(unselected) - min(selected), clamped at 0 (0 for an exact top-k)."""
+    sel = torch.zeros_like(pre, dtype=torch.bool).scatter_(1, idx, True)
+    lo = torch.where(sel, pre, torch.full_like(pre, float("inf"))).min(1).values
+    hi = torch.where(sel, torch.full_like(pre, float("-inf")), pre).max(1).values
+    return (hi - lo).clamp_min(0)
+
+
 def topk_merge(cand_vals: Tensor, cand_idx: Tensor, k: int):
     """TP candidate merge -- fused_encoder.py:359-360: second top-k over the
     all-gathered ``[N, k*tp]`` candidates, then gather of the global indices.
@@ -342,6 +351,7 @@ def clt_train_step(
     divide_cross_layer: bool = False,
     acc_steps: int = 1,
     act_dtype=None,
+    forced_idx: Optional[list] = None,
 ) -> StepResult:
     """Explicit forward+backward of one FVU train step over all layers, in the
     order the reference's hook runs them (trainer.py:598-682): for each layer j
@@ -378,7 +388,14 @@ def clt_train_step(
         d = xs[j].shape[-1]
         xn = _normalize_in(lp, xs[j].to(dt), normalize_io)
         x_enc = xn if lp.transcode else xn - lp.b_decs[0].to(dt)  # sparse_coder.py:637-638
-        v, idx = encoder_forward(x_enc, lp.W_enc.to(dt), lp.b_enc.to(dt), k, None)
+        if forced_idx is None:
+            v, idx = encoder_forward(x_enc, lp.W_enc.to(dt), lp.b_enc.to(dt), k, None)
+        else:
+            # reduced-precision parity: evaluate the step on a GIVEN selection (the near-tie order of a
+            # bf16 GEMM is not reproducible across accumulation orders); validity of the selection is
+            # checked separately with topk_selection_slack().
+            idx = forced_idx[j]
+            v = encoder_preacts(x_enc, lp.W_enc.to(dt), lp.b_enc.to(dt), None).gather(1, idx)
         if act_dtype is not None:
             v = round_to(v, act_dtype)
         accts.append(v.clone())

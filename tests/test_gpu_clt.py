@@ -1,0 +1,238 @@
+"""GPU parity of the host mirror (SparseCoder / MidDecoder / CrossLayerRunner / Trainer) against
+(a) golden vectors produced by the reference itself, fp32, rtol 1e-5, index sets bit-exact;
+(b) the CPU oracle in the bf16 mode, rtol 1e-2 (BASELINE.json)."""
+import math
+
+import pytest
+import torch
+
+from conftest import golden_grad_name, golden_layers, load_golden
+from oracle import clt_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build_sae(t, meta, l, single, dtype=torch.float32, cfg_over=None):
+    from clt_training_amd import SparseCoder, SparseCoderConfig
+
+    cfgd = dict(meta["cfg"])
+    if not single:
+        cfgd["n_targets"] = min(meta["cross_layer"], meta["L"] - l)
+    cfgd.update(cfg_over or {})
+    cfg = SparseCoderConfig(**cfgd)
+    sae = SparseCoder(meta["d"], cfg, DEV, dtype=torch.float32)
+    pre = "p." if single else f"p.{l}."
+    sd = sae.state_dict()
+    with torch.no_grad():
+        for k, v in t.items():
+            if k.startswith(pre):
+                name = k[len(pre):]
+                sd[name].copy_(v.to(DEV).to(sd[name].dtype))
+    return sae
+
+
+def run_reference_sequence(saes, xs, ys, mask):
+    """The hook sequence of trainer.py:598-682."""
+    from clt_training_amd import CrossLayerRunner
+
+    runner = CrossLayerRunner()
+    outs, encs = [], []
+    for l, sae in enumerate(saes):
+        enc = runner.encode(xs[l], sae)
+        out = runner.decode(enc, ys[l], module_name=f"layers.{l}", detach_grad=True, loss_mask=mask)
+        encs.append((enc.latent_indices, (enc.original_activations if hasattr(enc, "original_activations")
+                                          else enc.latent_acts).detach()))
+        outs.append(out)
+        out.fvu.backward()
+        runner.restore()
+    assert len(runner.outputs) == 0
+    return outs, encs
+
+
+@pytest.fixture()
+def fp32_exact():
+    import clt_training_amd.sparse_coder as sc
+
+    old = sc.AUTOCAST_ENABLED
+    sc.AUTOCAST_ENABLED = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+    sc.AUTOCAST_ENABLED = old
+
+
+def check_against_golden(t, saes, outs, encs, single):
+    for l, sae in enumerate(saes):
+        sfx = "" if single else f".{l}"
+        v, i = O.topk_merge(encs[l][1].float().cpu(), encs[l][0].cpu(), encs[l][0].shape[1])
+        assert torch.equal(i, t[f"idx{sfx}"])  # bit-exact index sets
+        torch.testing.assert_close(v, t[f"vals{sfx}"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(outs[l].sae_out.float().cpu(), t[f"sae_out{sfx}"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(outs[l].fvu.float().cpu(), t[f"fvu{sfx}"], rtol=1e-5, atol=1e-6)
+        gpre = "g." if single else f"g.{l}."
+        seen = 0
+        for key, ref in t.items():
+            if key.startswith(gpre):
+                p = dict(sae.named_parameters())[key[len(gpre):]]
+                assert p.grad is not None, key
+                torch.testing.assert_close(p.grad.float().cpu(), ref, rtol=1e-5, atol=2e-7, msg=lambda m: f"{key}: {m}")
+                seen += 1
+        assert seen >= 4
+
+
+@pytest.mark.parametrize("name", ["single_transcoder_skip", "single_transcoder_scale_norm", "single_sae"])
+def test_single_layer_vs_reference_golden(name, fp32_exact):
+    t, meta = load_golden(name)
+    sae = build_sae(t, meta, 0, True)
+    mask = t["mask"].to(DEV) if "mask" in t else None
+    outs, encs = run_reference_sequence([sae], [t["x"].to(DEV)], [t["y"].to(DEV)], mask)
+    check_against_golden(t, [sae], outs, encs, True)
+    if name == "single_sae":
+        sae.remove_gradient_parallel_to_decoder_directions()
+        torch.testing.assert_close(sae.W_dec.grad.cpu(), t["g_proj.W_dec"], rtol=1e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3"])
+def test_clt_vs_reference_golden(name, fp32_exact):
+    t, meta = load_golden(name)
+    L = meta["L"]
+    saes = [build_sae(t, meta, l, False) for l in range(L)]
+    xs = [t[f"x.{l}"].to(DEV) for l in range(L)]
+    ys = [t[f"y.{l}"].to(DEV) for l in range(L)]
+    outs, encs = run_reference_sequence(saes, xs, ys, t["mask"].to(DEV))
+    check_against_golden(t, saes, outs, encs, False)
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["clt_none_div_scale_norm_L4", "clt_concat_L3"])
+def test_clt_bf16_mode_vs_oracle(name):
+    """Mode B (bf16 encoder / decoder weights, bf16 autocast): rtol 1e-2 against the oracle
+    evaluated on the same bf16-rounded weights."""
+    t, meta = load_golden(name)
+    L = meta["L"]
+    saes = [build_sae(t, meta, l, False, cfg_over=dict(dtype="bfloat16")) for l in range(L)]
+    assert saes[0].encoder.weight.dtype == torch.bfloat16 and saes[0].W_dec.dtype == torch.bfloat16
+    xs = [t[f"x.{l}"].to(torch.bfloat16) for l in range(L)]
+    ys = [t[f"y.{l}"].to(torch.bfloat16) for l in range(L)]
+    outs, encs = run_reference_sequence(saes, [x.to(DEV) for x in xs], [y.to(DEV) for y in ys], t["mask"].to(DEV))
+    layers = golden_layers(t, meta, L)
+    for lp, sae in zip(layers, saes):  # the oracle sees exactly the rounded parameters
+        lp.W_enc = sae.encoder.weight.detach().float().cpu()
+        lp.b_enc = sae.encoder.bias.detach().float().cpu()
+        lp.W_decs = [(sae.W_decs[i] if hasattr(sae, "W_decs") else sae.W_dec).detach().float().cpu()
+                     for i in range(len(lp.W_decs))]
+    cfg = meta["cfg"]
+    forced = [e[0].cpu() for e in encs]
+    res = O.clt_train_step(layers, [x.float() for x in xs], [y.float() for y in ys], t["mask"], cfg["k"],
+                           coalesce=cfg.get("coalesce_topk", "none"), normalize_io=cfg.get("normalize_io", False),
+                           divide_cross_layer=cfg.get("divide_cross_layer", False), act_dtype=torch.bfloat16,
+                           forced_idx=forced)
+    d = meta["d"]
+    for l, sae in enumerate(saes):
+        # the selection must be an exact top-k of the fp64 pre-activations up to bf16 resolution
+        lp = layers[l]
+        xn = xs[l].double() * (d**0.5 / lp.in_norm.double()) if cfg.get("normalize_io") else xs[l].double()
+        pre = O.encoder_preacts(xn, lp.W_enc.double(), lp.b_enc.double(), None)
+        slack = O.topk_selection_slack(pre, forced[l])
+        assert float((slack / pre.max(1).values).max()) < 2e-2
+        assert all(len(set(r.tolist())) == cfg["k"] for r in forced[l])
+        torch.testing.assert_close(encs[l][1].float().cpu(), res.top_acts[l].float(), rtol=1e-2, atol=1e-2)
+        assert rel_err(outs[l].sae_out.float().cpu(), res.sae_outs[l]) < 1e-2
+        assert abs(float(outs[l].fvu) - float(res.fvus[l])) < 1e-2 * float(res.fvus[l])
+        for n, p in sae.named_parameters():
+            ref = res.grads[l][golden_grad_name(n)]
+            if ref.norm() > 0:
+                assert rel_err(p.grad.detach().float().cpu(), ref) < 2e-2, (l, n, rel_err(p.grad.detach().float().cpu(), ref))
+
+
+def set_rows(idx):
+    return [frozenset(r.tolist()) for r in idx]
+
+
+def test_trainer_three_steps_vs_oracle(fp32_exact):
+    """Trainer (step-0 init, runner order, Adam, WarmupLinearSchedule) against the oracle restatement."""
+    from clt_training_amd import SparseCoderConfig, TrainConfig, Trainer
+
+    L, d, N, k, cross = 3, 32, 64, 4, 2
+    hooks = [f"h.{i}.mlp" for i in range(L)]
+    g = torch.Generator().manual_seed(0)
+    steps = 4
+    data = []
+    for s in range(steps):
+        b = {}
+        for h in hooks:
+            x = torch.randn(N, d, generator=g) + 0.2 * torch.randn(d, generator=g)
+            y = 0.5 * x + 0.5 * torch.randn(N, d, generator=g)
+            b[h] = (x, y)
+        m = torch.ones(N, dtype=torch.bool)
+        m[::16] = False
+        b["loss_mask"] = m
+        data.append(b)
+    sae_cfg = SparseCoderConfig(transcode=True, expansion_factor=4, k=k, skip_connection=True, normalize_io=True,
+                                post_encoder_scale=True)
+    cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=cross, optimizer="adam", lr=1e-2, lr_warmup_steps=2)
+    gpu_data = [{h: tuple(v.to(DEV) for v in val) if isinstance(val, tuple) else val.to(DEV) for h, val in b.items()}
+                for b in data]
+    tr = Trainer(cfg, gpu_data, device=DEV)
+    # decoders start at zero in a transcoder: give them (and post_enc) non-trivial values
+    gi = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for sae in tr.saes.values():
+            for n, p in sae.named_parameters():
+                if n.startswith("W_dec"):
+                    p.copy_((torch.randn(p.shape, generator=gi) / math.sqrt(d)).to(DEV))
+                if n.startswith("post_encs"):
+                    p.copy_((0.05 * torch.randn(p.shape, generator=gi)).to(DEV))
+
+    # ---- oracle trainer
+    layers = []
+    for l, h in enumerate(hooks):
+        sae = tr.saes[h]
+        sd = {n: p.detach().float().cpu().clone() for n, p in sae.state_dict().items()}
+        T = sae.cfg.n_targets
+        def lst(stem, plural):
+            return [sd[stem if i == 0 else f"{plural}.{i}"] for i in range(T)]
+        layers.append(O.LayerParams(sd["encoder.weight"], sd["encoder.bias"], lst("W_dec", "W_decs"),
+                                    lst("b_dec", "b_decs"), lst("W_skip", "W_skips"),
+                                    [sd[f"post_encs.{i}"] for i in range(T)],
+                                    [sd[f"post_enc_scales.{i}"] for i in range(T)], T, sd["in_norm"], sd["out_norm"], True))
+    state = [dict() for _ in range(L)]
+    fvu_hist = []
+    for s in range(steps):
+        if s == 0:
+            for l, h in enumerate(hooks):
+                O.step0_init(layers[l], data[0][h][0], data[0][h][1], True)
+        res = O.clt_train_step(layers, [data[s][h][0] for h in hooks], [data[s][h][1] for h in hooks],
+                               data[s]["loss_mask"], k, normalize_io=True)
+        fvu_hist.append([float(f) for f in res.fvus])
+        lr = 1e-2 * O.warmup_linear_factor(s, 2, steps)
+        for l in range(L):
+            lp = layers[l]
+            tensors = {"W_enc": lp.W_enc, "b_enc": lp.b_enc}
+            for i in range(lp.n_targets):
+                tensors[f"W_decs.{i}"] = lp.W_decs[i]; tensors[f"b_decs.{i}"] = lp.b_decs[i]
+                tensors[f"W_skips.{i}"] = lp.W_skips[i]; tensors[f"post_encs.{i}"] = lp.post_encs[i]
+                tensors[f"post_enc_scales.{i}"] = lp.post_enc_scales[i]
+            for n, p in tensors.items():
+                m, v = state[l].get(n, (torch.zeros_like(p).double(), torch.zeros_like(p).double()))
+                pn, m, v = O.adam_step(p, res.grads[l][n], m, v, s + 1, lr)
+                p.copy_(pn.float())
+                state[l][n] = (m, v)
+    # ---- HIP trainer
+    got_fvu = []
+    for b in gpu_data:
+        f = tr.step(b)
+        got_fvu.append([float(f[h]) for h in hooks])
+    torch.testing.assert_close(torch.tensor(got_fvu), torch.tensor(fvu_hist), rtol=2e-4, atol=1e-6)
+    for l, h in enumerate(hooks):
+        sae = tr.saes[h]
+        torch.testing.assert_close(sae.encoder.weight.detach().cpu(), layers[l].W_enc, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(sae.encoder.bias.detach().cpu(), layers[l].b_enc, rtol=1e-4, atol=1e-5)
+        for i in range(sae.cfg.n_targets):
+            torch.testing.assert_close(sae.W_decs[i].detach().cpu(), layers[l].W_decs[i], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(sae.b_decs[i].detach().cpu(), layers[l].b_decs[i], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(sae.W_skips[i].detach().cpu(), layers[l].W_skips[i], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(sae.post_enc_scales[i].detach().cpu(), layers[l].post_enc_scales[i], rtol=1e-4, atol=1e-5)
