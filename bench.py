@@ -1,0 +1,198 @@
+"""bench.py -- train tokens/s of the GPT-2 CLT (12 layers, cross_layer=12, expansion 128, k=32,
+skip connection, bf16) fwd + bwd + Adam step on MI355X, with synthetic cached activations.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job tokens/s, plus
+`roofline` for the dominant kernel (HIP events on the launch stream, over the timed region),
+`kernels` (every C-ABI kernel: launches/step, mean ms, achieved vs peak) and `cpu_baseline`
+(the torch-CPU restatement of the reference's eager step timed on this box's host cores)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_BF16 = 2.5e15   # MI355X dense bf16 MFMA, FLOP/s (MI355X_MICROARCH.md)
+PEAK_HBM = 8.0e12    # HBM3E, B/s
+
+
+def synth_batches(hooks, N, d, n_batches, dtype, device, seed=0):
+    """x = randn + 0.1*randn(d); y = x @ R_l + 0.5*randn; mask drops token 0 of every 128."""
+    out = []
+    for s in range(n_batches):
+        b = {}
+        for l, h in enumerate(hooks):
+            g = torch.Generator(device=device).manual_seed(1000 * s + l + seed)
+            gr = torch.Generator(device=device).manual_seed(7 + l)
+            x = torch.randn(N, d, generator=g, device=device) + 0.1 * torch.randn(d, generator=g, device=device)
+            R = torch.randn(d, d, generator=gr, device=device) / d**0.5
+            y = x @ R + 0.5 * torch.randn(N, d, generator=g, device=device)
+            b[h] = (x.to(dtype), y.to(dtype))
+        m = torch.ones(N, dtype=torch.bool, device=device)
+        m[::128] = False
+        b["loss_mask"] = m
+        out.append(b)
+    return out
+
+
+def algorithmic_work(name, N, d, M, k, es, P_total):
+    """Algorithmic flops / bytes per launch -> (amount, 'flop'|'byte')."""
+    if name == "clt_encoder_gemm_relu":
+        return 2.0 * N * d * M, "flop"
+    if name == "clt_topk_rows":
+        return N * M * es, "byte"
+    if name in ("clt_decode_fwd", "clt_decode_bwd_acts"):
+        return es * N * (k + 1) * d, "byte"
+    if name == "clt_spt_dense":
+        return es * (M * d + N * k * d), "byte"
+    if name == "clt_adam_step":
+        return 7.0 * es * P_total, "byte"
+    if name == "clt_fvu_fwd_bwd":
+        return N * d * es * 6, "byte"
+    return None, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tokens", type=int, default=8192, help="tokens per step per GPU")
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--d-model", type=int, default=768)
+    ap.add_argument("--expansion", type=int, default=128)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from clt_training_amd import SparseCoderConfig, TrainConfig, Trainer
+    from clt_training_amd import hip_ops
+
+    L, d, k = args.layers, args.d_model, args.k
+    M = d * args.expansion
+    N = args.tokens
+    hooks = [f"h.{i}.mlp" for i in range(L)]
+    sae_cfg = SparseCoderConfig(dtype=args.dtype if args.dtype == "bfloat16" else "none", expansion_factor=args.expansion,
+                                k=k, transcode=True, skip_connection=True)
+    cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=L, optimizer="adam", lr=2e-4, lr_warmup_steps=50,
+                      log_to_wandb=False)
+    act_dtype = torch.bfloat16 if args.dtype == "bfloat16" else torch.float32
+    es = 2 if args.dtype == "bfloat16" else 4
+
+    if world > 1:
+        from clt_training_amd.tp import TPTrainer
+
+        batches = synth_batches(hooks, N, d, 2, act_dtype, device, seed=rank * 7919)
+        trainer = TPTrainer(cfg, batches, device=device, num_batches=10_000)
+        parallelism = f"tp{world}"
+    else:
+        batches = synth_batches(hooks, N, d, 2, act_dtype, device)
+        trainer = Trainer(cfg, batches, device=device, num_batches=10_000)
+        parallelism = "single"
+    # transcoder decoders are zero-initialised (sparse_coder.py:304-338): use the "warm" variant so
+    # the decode / backward arithmetic is not trivially zero
+    with torch.no_grad():
+        for sae in trainer.saes.values():
+            g = torch.Generator(device=device).manual_seed(1)
+            for n, p in sae.named_parameters():
+                if n.startswith("W_dec"):
+                    p.copy_((0.02 * torch.randn(p.shape, generator=g, device=device)).to(p.dtype))
+                elif n.startswith("post_encs"):
+                    p.copy_(0.01 * torch.randn(p.shape, generator=g, device=device))
+    P_total = sum(p.numel() for sae in trainer.saes.values() for p in sae.parameters())
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(batches[i % len(batches)])
+    barrier()
+    prof = hip_ops.KernelProfile()
+    hip_ops.PROFILE = prof
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        fv = trainer.step(batches[i % len(batches)])
+    barrier()
+    dt = time.perf_counter() - t0
+    hip_ops.PROFILE = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    tokens_per_step = N * world
+    value = tokens_per_step * args.steps / dt
+
+    if rank == 0:
+        # ---- per-kernel table and the dominant kernel's roofline
+        Ml = M // world
+        kernels = {}
+        dominant, dom_ms = None, -1.0
+        for name, (cnt, ms) in prof.summary().items():
+            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_total // world)
+            ent = {"launches_per_step": cnt / args.steps, "mean_ms": round(ms, 4),
+                   "ms_per_step": round(ms * cnt / args.steps, 3)}
+            if amount is not None:
+                rate = amount / (ms * 1e-3)
+                peak = PEAK_BF16 if kind == "flop" else PEAK_HBM
+                ent.update({"achieved": round(rate / (1e12 if kind == "flop" else 1e9), 1),
+                            "unit": "TFLOP/s" if kind == "flop" else "GB/s", "frac": round(rate / peak, 4),
+                            "bound": "mfma" if kind == "flop" else "hbm"})
+                if ent["ms_per_step"] > dom_ms:
+                    dominant, dom_ms = name, ent["ms_per_step"]
+            kernels[name] = ent
+        roofline = None
+        if dominant:
+            e = kernels[dominant]
+            roofline = {"kernel": dominant, "bound": e["bound"], "achieved": e["achieved"],
+                        "peak": 2500.0 if e["bound"] == "mfma" else 8000.0, "unit": e["unit"], "frac": e["frac"],
+                        "traffic": None}
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, str(ROOT))
+            from oracle import cpu_baseline
+
+            cpu = cpu_baseline.run(L=2, d=d, M=M, k=k, N=1024, min_seconds=args.cpu_seconds, full_L=L)
+        line = {
+            "metric": "train tokens/sec, GPT-2 CLT (exp128,k32) fwd+bwd+Adam", "value": round(value, 1),
+            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "config": {"workload": f"GPT-2 small CLT: {L} layers, cross_layer={L}, d={d}, latents={M}, k={k}, "
+                                   f"skip_connection, {args.dtype} weights, Adam; {N} tokens/step/GPU "
+                                   f"(BASELINE.json configs[1])",
+                       "tokens_per_step": tokens_per_step, "params": P_total, "parallelism": parallelism},
+            "fvu_last": round(float(sum(float(v) for v in fv.values()) / len(fv)), 5),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .hip_ops import _DT, _stream
+from .hip_ops import _DT, _call, _stream
 
 CHUNK = 1 << 16
 
@@ -74,7 +74,6 @@ class Adam(torch.optim.Optimizer):
             r.lr = float(self.param_groups[gi]["lr"])
             r.p_dtype, r.g_dtype = _DT[p.dtype], _DT[g.dtype]
         devt.copy_(host, non_blocking=True)
-        _lib.check(
-            _lib.load().clt_adam_step(C.c_void_p(devt.data_ptr()), len(live), C.c_void_p(ct.data_ptr()),
-                                      C.c_void_p(cs.data_ptr()), ct.numel(), CHUNK, 1.0, float(betas[0]), float(betas[1]),
-                                      float(eps), self._step, _stream(devt)), "clt_adam_step")
+        _call("clt_adam_step", C.c_void_p(devt.data_ptr()), len(live), C.c_void_p(ct.data_ptr()),
+              C.c_void_p(cs.data_ptr()), ct.numel(), CHUNK, 1.0, float(betas[0]), float(betas[1]), float(eps),
+              self._step, _stream(devt))
