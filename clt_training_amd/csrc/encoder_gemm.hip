@@ -7,17 +7,24 @@
 // ONE token and runs of 4 consecutive latents, i.e. 8/16 contiguous bytes of a pre row,
 // and a per-token threshold test for a fused top-k filter is a per-lane scalar compare.
 //
-// Tile: 128 latents x 128 tokens x (128 bytes of K) per step, 4 waves as 2 x 2, each wave
-// 64 x 64 = 2 x 2 MFMA tiles (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32).
-// Staging: global_load_lds 16 B/lane straight into a double-buffered LDS image
-// (2 x 2 x 16 KiB); the image is lane-linear, the bank swizzle
-// (chunk ^= (row >> 1) & 7) is applied to the per-lane SOURCE address and to the
-// ds_read_b128 address (cdna_hip_programming.md rule 21).  Out-of-range rows / K tails
-// read a 16-byte zero chunk, so every shape with d % 8 == 0 (bf16) or d % 4 == 0 (f32)
-// runs on the same path.  Workgroups are renumbered so that each XCD walks a contiguous
-// range of (token panel, latent tile) pairs: a panel of 16 token tiles of x stays in the
-// XCD's 4 MiB L2 while W tiles stream through.
-// MFMA-bound: 2 * N * M * d flops.
+// Structure (persistent, one 512-thread workgroup per CU):
+//   tile 256 latents x 256 tokens x (64 bytes of K per step); 8 waves as 2 (latent) x 4
+//   (token), each wave 128 x 64 = 4 x 2 MFMA tiles (v_mfma_f32_32x32x16_bf16 /
+//   v_mfma_f32_32x32x2_f32), 128 accumulator VGPRs;
+//   staging by global_load_lds, 16 B per lane, into a 4-deep ring of lane-linear LDS images
+//   (4 stages x (2 operands x 16 KiB + 1 KiB of bias) = 132 KiB, 64 bytes of K per stage, counted
+//   s_waitcnt vmcnt(10): three k-steps of LDS-DMA stay in flight); the bank swizzle chunk ^= (row >> 2) & 3
+//   is applied to the per-lane SOURCE address and to the ds_read_b128 address
+//   (cdna_hip_programming.md rule 21); rows beyond M / N and K tails read a 16-byte zero
+//   chunk, so every shape with 16-byte rows runs on the same path;
+//   the (tile, k-step) sequence of a workgroup is flattened: the loads of the NEXT tile's
+//   first k-step are already in flight while the current tile's epilogue runs;
+//   workgroups are numbered so that the 32 workgroups of an XCD work on neighbouring
+//   (token panel, latent tile, token tile) ids: an 8-tile token panel of x (3 MiB) stays in the
+//   XCD's 4 MiB L2 while W tiles stream through once per panel.
+// MFMA-bound: 2 * N * M * d flops per launch.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace clt {
@@ -27,35 +34,92 @@ __device__ uint4 g_zero_chunk[1];  // 16 zero bytes, source for padding lanes
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int TM = 128;   // latents per tile
-constexpr int TN = 128;   // tokens per tile
-constexpr int ROWB = 128; // bytes of K per row per step
-constexpr int TILE_BYTES = TM * ROWB;  // 16 KiB per operand per buffer
-constexpr int PANEL = 16;              // token tiles per L2 panel
+constexpr int TM = 256;    // latents per tile
+constexpr int TN = 256;    // tokens per tile
+constexpr int ROWB = 64;   // bytes of K per row per step
+constexpr int OP_BYTES = TM * ROWB;  // 16 KiB per operand per stage
+constexpr int NSTAGE = 4;            // LDS ring: 3 k-steps of LDS-DMA in flight behind the one being multiplied
+constexpr int BIAS_OFF = 2 * OP_BYTES;      // each stage also carries the tile's 256 bias values (<= 1 KiB)
+constexpr int STAGE_BYTES = 2 * OP_BYTES + 1024;
+constexpr int PANEL = 8;             // token tiles per L2 panel
+constexpr int NTHREADS = 512;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-// Stage one 128-row x 128-byte operand tile. 16 pieces of 1 KiB; wave w issues pieces w, w+4, w+8, w+12.
-// Piece p covers LDS rows 8p .. 8p+7; lane l writes row 8p + l/8, chunk position l%8 and must
-// therefore fetch source chunk (l%8) ^ ((row >> 1) & 7) of that row.
-__device__ __forceinline__ void stage_tile(const char* __restrict__ base, int64_t row0, int64_t nrows, int64_t ld_bytes,
-                                           int kbyte0, int kbytes, char* lds_tile, int wave, int lane) {
+struct TileCoord {
+  int64_t lat0, tok0;
+};
+
+__device__ __forceinline__ TileCoord tile_of(int64_t id, int64_t nlt, int64_t ntt) {
+  const int64_t full = nlt * PANEL;
+  const int64_t p = id / full;
+  const int64_t rem = id - p * full;
+  const int64_t pt = min((int64_t)PANEL, ntt - p * PANEL);
+  TileCoord c;
+  c.lat0 = (rem / pt) * TM;
+  c.tok0 = (p * PANEL + rem % pt) * TN;
+  return c;
+}
+
+// One LDS-DMA of 16 B per lane: LDS[dst + 16 * lane] = *src.  Issued from inline asm so that hipcc
+// neither counts it nor drains it: with the builtin, hipcc puts s_waitcnt vmcnt(0) in front of the
+// next ds_read (it cannot prove that the DMA target and the tile being read are different buffers),
+// which serialises every prefetch (cdna_hip_programming.md, "Pipelining across barriers", 5.7 item 1).
+// Completion is waited for by the explicit s_waitcnt vmcnt(0) in front of the k-step barrier.
+__device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
+  const unsigned dst = (unsigned)(uintptr_t)(lds_ptr_t)lds_dst;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(dst)
+      : "memory");
+}
+
+// Stage one k-step of both operand tiles.  An operand stage is 16 pieces of 1 KiB (16 rows x 64 B);
+// wave w issues pieces w and w+8 of each operand (4 LDS-DMAs per wave per k-step).  Lane l of a piece
+// writes LDS row 16*piece + l/4, chunk position l%4, and therefore fetches source chunk
+// (l%4) ^ ((row >> 2) & 3).
+constexpr int GLDS_PER_STEP = 5;  // 2 W pieces + 2 x pieces + this wave's 32 bias values
+__device__ __forceinline__ void stage_step(const char* __restrict__ Wb, const char* __restrict__ xb,
+                                           const char* __restrict__ bias, int bias_esize, TileCoord tc,
+                                           int64_t M, int64_t N, int64_t ld_bytes, int kbyte0, int kbytes,
+                                           char* buf, int wave, int lane) {
+  const char* zero = reinterpret_cast<const char*>(g_zero_chunk);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave + 4 * i;
-    const int r = piece * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    const int64_t grow = row0 + r;
-    const int kb = kbyte0 + c * 16;
-    const char* src = (grow < nrows && kb < kbytes) ? base + grow * ld_bytes + kb
-                                                     : reinterpret_cast<const char*>(g_zero_chunk);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds_tile + piece * 1024), 16, 0, 0);
+  for (int op = 0; op < 2; ++op) {
+    const char* base = op == 0 ? Wb : xb;
+    const int64_t row0 = op == 0 ? tc.lat0 : tc.tok0;
+    const int64_t nrows = op == 0 ? M : N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave + 8 * i;
+      const int r = piece * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      const int64_t grow = row0 + r;
+      const int kb = kbyte0 + c * 16;
+      const char* src = (grow < nrows && kb < kbytes) ? base + grow * ld_bytes + kb : zero;
+      glds16(src, buf + op * OP_BYTES + piece * 1024);
+    }
+  }
+  // bias of latents [lat0 + 32*wave, +32): 8 (f32) or 4 (bf16) lanes of one exec-masked LDS-DMA.  Every wave
+  // issues it on every k-step (even without a bias), so that the counted vmcnt waits are the same everywhere.
+  const int nl = 32 * bias_esize / 16;
+  if (lane < nl) {
+    const int epc = 16 / bias_esize;  // elements per 16-byte chunk
+    const int64_t lat = tc.lat0 + 32 * wave + lane * epc;
+    const char* src = (bias && lat + epc <= M) ? bias + lat * bias_esize : zero;
+    glds16(src, buf + BIAS_OFF + wave * nl * 16);
   }
 }
 
 __device__ __forceinline__ uint4 lds_frag(const char* lds_tile, int row, int chunk) {
-  const int pos = chunk ^ ((row >> 1) & 7);
+  const int pos = chunk ^ ((row >> 2) & 3);
   return *reinterpret_cast<const uint4*>(lds_tile + row * ROWB + pos * 16);
 }
 
@@ -74,110 +138,188 @@ __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, 
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
-// Bijective XCD-aware renumbering (cdna_hip_programming.md, T1): blocks b and b+8 share an XCD;
-// give each XCD group a contiguous range of logical ids.
-__device__ __forceinline__ int64_t xcd_remap(int64_t orig, int64_t nwg) {
-  const int64_t q = nwg / 8, r = nwg % 8, x = orig % 8;
-  const int64_t start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-  return start + orig / 8;
+// Bias of 8 consecutive latents starting at the WAVE-UNIFORM index lat8.  The address is uniform and the
+// buffer is const __restrict__, so hipcc emits scalar loads (s_load_dwordx4/x8, lgkmcnt): they neither
+// occupy vector registers nor share the vmcnt queue with the LDS-DMA prefetch and the epilogue stores.
+__device__ __forceinline__ void load_bias8(const void* __restrict__ bias, int bias_dtype, int64_t lat8, int64_t M,
+                                           float (&b)[8]) {
+  if (!bias) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = 0.f;
+  } else if (lat8 + 7 < M) {
+    if (bias_dtype == CLT_BF16) {
+      const uint16_t* p = reinterpret_cast<const uint16_t*>(bias) + lat8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[q] = bf16_bits_to_f32(p[q]);
+    } else {
+      const float* p = reinterpret_cast<const float*>(bias) + lat8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[q] = p[q];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = lat8 + q < M ? load_scalar(bias, bias_dtype, lat8 + q) : 0.f;
+  }
 }
 
 template <typename T, typename OT>
-__global__ __launch_bounds__(256, 2) void encoder_gemm_kernel(const T* __restrict__ x, const T* __restrict__ W,
-                                                               const void* __restrict__ bias, int bias_dtype,
-                                                               OT* __restrict__ pre, int64_t N, int64_t M, int d,
-                                                               int64_t nlt, int64_t ntt) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];  // [buf][A|B][16 KiB]
+__global__ __launch_bounds__(NTHREADS, 2) void encoder_gemm_kernel(const T* __restrict__ x, const T* __restrict__ W,
+                                                                    const void* __restrict__ bias, int bias_dtype,
+                                                                    OT* __restrict__ pre, int64_t N, int64_t M, int d,
+                                                                    int64_t nlt, int64_t ntt, int dbg) {
+  __shared__ __attribute__((aligned(16))) char lds[NSTAGE * STAGE_BYTES];  // ring of [W | x] k-steps
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r32 = lane & 31, h = lane >> 5;
 
-  // ---- logical tile id -> (token panel, latent tile, token tile)
-  const int64_t id = xcd_remap(blockIdx.x, nlt * ntt);
-  const int64_t full = nlt * PANEL;
-  int64_t p = id / full;
-  int64_t rem = id - p * full;
-  const int64_t pt = min((int64_t)PANEL, ntt - p * PANEL);
-  const int64_t lt = rem / pt, tt = p * PANEL + rem % pt;
-  const int64_t lat0 = lt * TM, tok0 = tt * TN;
+  // ---- this workgroup's tile ids: XCD group x = blockIdx % 8 owns a contiguous id range;
+  //      its workgroups walk it with stride (#workgroups in the group)
+  const int64_t ntiles = nlt * ntt;
+  const int64_t xg = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int64_t nbx = (gridDim.x - xg + 7) >> 3;
+  const int64_t q = ntiles >> 3, rr = ntiles & 7;
+  const int64_t xstart = xg < rr ? xg * (q + 1) : rr * (q + 1) + (xg - rr) * q;
+  const int64_t xcount = q + (xg < rr ? 1 : 0);
+  const int64_t my_tiles = bi < xcount ? (xcount - bi + nbx - 1) / nbx : 0;
+  if (my_tiles == 0) return;
 
   const int kbytes = d * (int)sizeof(T);
   const int nsteps = (kbytes + ROWB - 1) / ROWB;
   const int64_t ld_bytes = (int64_t)kbytes;
   const char* Wb = reinterpret_cast<const char*>(W);
   const char* xb = reinterpret_cast<const char*>(x);
+  const char* bias_b = reinterpret_cast<const char*>(bias);
+  const int bias_esize = bias_dtype == CLT_BF16 ? 2 : 4;
+  const bool bias_lds = (M & 7) == 0;  // otherwise a 16-byte bias chunk could straddle the end of the array
 
-  f32x16 acc[2][2];
+  f32x16 acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  stage_tile(Wb, lat0, M, ld_bytes, 0, kbytes, lds, wave, lane);
-  stage_tile(xb, tok0, N, ld_bytes, 0, kbytes, lds + TILE_BYTES, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int r32 = lane & 31, h = lane >> 5;
-  for (int t = 0; t < nsteps; ++t) {
-    char* cur = lds + (t & 1) * 2 * TILE_BYTES;
-    char* nxt = lds + ((t + 1) & 1) * 2 * TILE_BYTES;
-    if (t + 1 < nsteps) {
-      stage_tile(Wb, lat0, M, ld_bytes, (t + 1) * ROWB, kbytes, nxt, wave, lane);
-      stage_tile(xb, tok0, N, ld_bytes, (t + 1) * ROWB, kbytes, nxt + TILE_BYTES, wave, lane);
+  // ---- flattened (tile, k-step) sequence with a 4-deep LDS ring
+  const int64_t total = my_tiles * nsteps;
+  int64_t t_idx = 0;          // tile being multiplied (index among my tiles)
+  TileCoord cur = tile_of(xstart + bi, nlt, ntt);
+  int ks = 0;                 // its k-step
+  int64_t ld_s = 0;           // next (tile, k-step) to stage
+  int64_t ld_t = 0;
+  int ld_ks = 0;
+  TileCoord ld_tc = cur;
+  auto issue_next = [&]() {
+    if (ld_s < total && !(dbg & 4)) {
+      stage_step(Wb, xb, bias_b, bias_esize, ld_tc, M, N, ld_bytes, ld_ks * ROWB, kbytes,
+                 lds + (ld_s % NSTAGE) * STAGE_BYTES, wave, lane);
     }
+    ++ld_s;
+    if (++ld_ks == nsteps) {
+      ld_ks = 0;
+      ++ld_t;
+      if (ld_t < my_tiles) ld_tc = tile_of(xstart + bi + ld_t * nbx, nlt, ntt);
+    }
+  };
+  issue_next();
+  issue_next();
+  issue_next();
+
+  for (int64_t s = 0; s < total; ++s) {
+    // stage s has landed once at most the LDS-DMAs of the (up to two) younger stages are outstanding
+    const int64_t younger = min((int64_t)2, total - 1 - s);
+    if (younger == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave's share of stage s is in LDS; every wave is done reading stage s-1
+    const bool last_k = ks + 1 == nsteps;
+    if (!last_k) issue_next();  // into the slot of stage s-1
+    char* cb = lds + (s % NSTAGE) * STAGE_BYTES;
+    // ---- MFMA over this k-step
+    if (!(dbg & 2))
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      uint4 a[2], b[2];
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 a[4], b[2];
+      if (dbg & 8) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = lds_frag(cur, wm * 64 + i * 32 + r32, 2 * kk + h);
+        for (int i = 0; i < 4; ++i) a[i] = make_uint4(lane + i, lane, s, kk);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = lds_frag(cur + TILE_BYTES, wn * 64 + j * 32 + r32, 2 * kk + h);
+        for (int j = 0; j < 2; ++j) b[j] = make_uint4(lane, lane + j, s, kk);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i) a[i] = lds_frag(cb, wm * 128 + i * 32 + r32, 2 * kk + h);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = lds_frag(cb + OP_BYTES, wn * 64 + j * 32 + r32, 2 * kk + h);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) mma_step<T>(a[i], b[j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---- epilogue: + bias, ReLU, one rounding, 4 consecutive latents per store
+    // ---- epilogue at the end of a tile: + bias, ReLU, one rounding, 4 consecutive latents per store
+    if (last_k) {
+      // token-major store order: the 16 stores of one pre row (512 contiguous bytes per wave) go out back to
+      // back, so L2 assembles whole lines (interleaving two rows measured 35 % slower for the whole kernel)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t tok = tok0 + wn * 64 + j * 32 + r32;
-    if (tok >= N) continue;
-    OT* prow = pre + tok * M;
+      for (int j = 0; j < 2; ++j) {
+        const int64_t tok = cur.tok0 + wn * 64 + j * 32 + r32;
+        OT* prow = pre + tok * M;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int64_t lat = lat0 + wm * 64 + i * 32 + 8 * g + 4 * h;
-        float v[4];
+          for (int g = 0; g < 4; ++g) {
+            const int off = wm * 128 + i * 32 + 8 * g;  // wave-uniform latent offset in the tile
+            const int64_t lat = cur.lat0 + off + 4 * h;
+            float bq[4], v[4];
+            if (bias_lds) {
+              if (bias_esize == 4) {
+                const float4 f = *reinterpret_cast<const float4*>(cb + BIAS_OFF + (off + 4 * h) * 4);
+                bq[0] = f.x; bq[1] = f.y; bq[2] = f.z; bq[3] = f.w;
+              } else {
+                const uint2 u = *reinterpret_cast<const uint2*>(cb + BIAS_OFF + (off + 4 * h) * 2);
+                bq[0] = bf16_lo(u.x); bq[1] = bf16_hi(u.x); bq[2] = bf16_lo(u.y); bq[3] = bf16_hi(u.y);
+              }
+            } else {
+              float b8[8];
+              load_bias8(bias, bias_dtype, cur.lat0 + off, M, b8);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float bq = 0.f;
-          if (bias && lat + q < M) bq = load_scalar(bias, bias_dtype, lat + q);
-          const float s = acc[i][j][4 * g + q] + bq;
-          v[q] = s > 0.f ? s : 0.f;
-        }
-        if (lat + 3 < M && (M & 3) == 0) {
-          if constexpr (sizeof(OT) == 2) {
-            uint2 u;
-            u.x = pack_bf16x2(v[0], v[1]);
-            u.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(prow + lat) = u;
-          } else {
-            *reinterpret_cast<float4*>(prow + lat) = make_float4(v[0], v[1], v[2], v[3]);
+              for (int qq = 0; qq < 4; ++qq) bq[qq] = h ? b8[4 + qq] : b8[qq];
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const float sum = acc[i][j][4 * g + qq] + bq[qq];
+              v[qq] = sum > 0.f ? sum : 0.f;
+              acc[i][j][4 * g + qq] = 0.f;
+            }
+            if (tok < N && !(dbg & 1)) {
+              if (lat + 3 < M && (M & 3) == 0) {
+                if constexpr (sizeof(OT) == 2) {
+                  uint2 u;
+                  u.x = pack_bf16x2(v[0], v[1]);
+                  u.y = pack_bf16x2(v[2], v[3]);
+                  *reinterpret_cast<uint2*>(prow + lat) = u;
+                } else {
+                  *reinterpret_cast<float4*>(prow + lat) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+              } else {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                  if (lat + qq < M) prow[lat + qq] = (OT)v[qq];
+              }
+            }
           }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (lat + q < M) prow[lat + q] = (OT)v[q];
         }
       }
+      ks = 0;
+      ++t_idx;
+      if (t_idx < my_tiles) cur = tile_of(xstart + bi + t_idx * nbx, nlt, ntt);
+      // the epilogue's stores are older than the LDS-DMAs issued now: the counted waits stay valid
+      issue_next();
+    } else {
+      ++ks;
     }
   }
 }
@@ -186,32 +328,48 @@ __global__ __launch_bounds__(256, 2) void encoder_gemm_kernel(const T* __restric
 
 using namespace clt;
 
+static int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 extern "C" int clt_encoder_gemm_relu(const void* x, const void* W, int in_dtype, const void* bias, int bias_dtype,
                                      void* pre, int out_dtype, int64_t N, int64_t M, int d, clt_stream_t stream) {
   CLT_CHECK_ARG(x && W && pre, "clt_encoder_gemm_relu: null pointer");
   CLT_CHECK_ARG(N >= 0 && M > 0 && d > 0 && M < (1ll << 31), "clt_encoder_gemm_relu: bad sizes");
   CLT_CHECK_ARG(valid_dtype(in_dtype) && valid_dtype(out_dtype) && (!bias || valid_dtype(bias_dtype)),
                 "clt_encoder_gemm_relu: bad dtype");
-  CLT_CHECK_ARG(aligned16(x) && aligned16(W) && aligned16(pre), "clt_encoder_gemm_relu: pointers must be 16-byte aligned");
+  CLT_CHECK_ARG(aligned16(x) && aligned16(W) && aligned16(pre) && (!bias || aligned16(bias)),
+                "clt_encoder_gemm_relu: pointers must be 16-byte aligned");
   CLT_UNSUPPORTED((d * (int)dtype_size(in_dtype)) % 16 == 0,
                   "clt_encoder_gemm_relu: d=%d must give rows that are a multiple of 16 bytes", d);
   if (N == 0) return CLT_OK;
   const int64_t nlt = (M + TM - 1) / TM, ntt = (N + TN - 1) / TN;
-  CLT_UNSUPPORTED(nlt * ntt < (1ll << 31), "clt_encoder_gemm_relu: too many tiles");
-  dim3 grid((unsigned)(nlt * ntt));
+  const int64_t ntiles = nlt * ntt;
+  const int64_t grid_n = ntiles < num_cus() ? ntiles : num_cus();
+  dim3 grid((unsigned)grid_n);
   hipStream_t st = (hipStream_t)stream;
+  const char* dbg_env = getenv("CLT_GEMM_DEBUG");  // timing experiments only (skip stores / MFMA / loads)
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
   if (in_dtype == CLT_BF16 && out_dtype == CLT_BF16)
-    hipLaunchKernelGGL((encoder_gemm_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)W,
-                       bias, bias_dtype, (bf16_t*)pre, N, M, d, nlt, ntt);
+    hipLaunchKernelGGL((encoder_gemm_kernel<bf16_t, bf16_t>), grid, dim3(NTHREADS), 0, st, (const bf16_t*)x,
+                       (const bf16_t*)W, bias, bias_dtype, (bf16_t*)pre, N, M, d, nlt, ntt, dbg);
   else if (in_dtype == CLT_BF16 && out_dtype == CLT_F32)
-    hipLaunchKernelGGL((encoder_gemm_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)W,
-                       bias, bias_dtype, (float*)pre, N, M, d, nlt, ntt);
+    hipLaunchKernelGGL((encoder_gemm_kernel<bf16_t, float>), grid, dim3(NTHREADS), 0, st, (const bf16_t*)x,
+                       (const bf16_t*)W, bias, bias_dtype, (float*)pre, N, M, d, nlt, ntt, dbg);
   else if (in_dtype == CLT_F32 && out_dtype == CLT_F32)
-    hipLaunchKernelGGL((encoder_gemm_kernel<float, float>), grid, dim3(256), 0, st, (const float*)x, (const float*)W,
-                       bias, bias_dtype, (float*)pre, N, M, d, nlt, ntt);
+    hipLaunchKernelGGL((encoder_gemm_kernel<float, float>), grid, dim3(NTHREADS), 0, st, (const float*)x,
+                       (const float*)W, bias, bias_dtype, (float*)pre, N, M, d, nlt, ntt, dbg);
   else
-    hipLaunchKernelGGL((encoder_gemm_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)x, (const float*)W,
-                       bias, bias_dtype, (bf16_t*)pre, N, M, d, nlt, ntt);
+    hipLaunchKernelGGL((encoder_gemm_kernel<float, bf16_t>), grid, dim3(NTHREADS), 0, st, (const float*)x,
+                       (const float*)W, bias, bias_dtype, (bf16_t*)pre, N, M, d, nlt, ntt, dbg);
   CLT_CHECK_LAUNCH("clt_encoder_gemm_relu");
   return CLT_OK;
 }
