@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default="engine", choices=["engine", "autograd"],
+                    help="engine: explicit CLTEngine (also the multi-GPU path); autograd: SparseCoder/CrossLayerRunner")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -102,12 +104,12 @@ def main():
     act_dtype = torch.bfloat16 if args.dtype == "bfloat16" else torch.float32
     es = 2 if args.dtype == "bfloat16" else 4
 
-    if world > 1:
+    if world > 1 or args.path == "engine":
         from clt_training_amd.tp import TPTrainer
 
         batches = synth_batches(hooks, N, d, 2, act_dtype, device, seed=rank * 7919)
         trainer = TPTrainer(cfg, batches, device=device, num_batches=10_000)
-        parallelism = f"tp{world}"
+        parallelism = f"tp{world}" if world > 1 else "single"
     else:
         batches = synth_batches(hooks, N, d, 2, act_dtype, device)
         trainer = Trainer(cfg, batches, device=device, num_batches=10_000)

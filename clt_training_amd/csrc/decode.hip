@@ -64,13 +64,36 @@ __device__ __forceinline__ float post_affine(float v, int r, const float* post_e
   return a;
 }
 
+// Latent sharding (tensor parallel): this GPU owns table rows [lat_begin, lat_begin + M).  Entries that
+// name another shard are skipped -- not masked: the valid entries of a 64-entry chunk are compacted to the
+// front of the wave (ds_permute push with a bijective destination map), so a shard pays k/tp row gathers
+// per token, not k (the reference masks and still gathers all k: utils.py:520-530).
+__device__ __forceinline__ int compact_dest(bool valid, bool active, int& n_valid) {
+  const unsigned long long mv = __ballot(valid), mi = __ballot(active && !valid);
+  n_valid = __popcll(mv);
+  const int pv = __builtin_amdgcn_mbcnt_hi((unsigned)(mv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mv, 0));
+  const int pi = __builtin_amdgcn_mbcnt_hi((unsigned)(mi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mi, 0));
+  const int n_act = __popcll(mv | mi);
+  // valid -> [0, n_valid), invalid-but-active -> [n_valid, n_act), inactive lanes keep the tail in lane order
+  const unsigned long long mo = ~(mv | mi);
+  const int po = __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0));
+  return valid ? pv : (active ? n_valid + pi : n_act + po);
+}
+__device__ __forceinline__ int permute_push_i(int dest_lane, int v) {
+  return __builtin_amdgcn_ds_permute(dest_lane << 2, v);
+}
+__device__ __forceinline__ float permute_push_f(int dest_lane, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_permute(dest_lane << 2, __float_as_int(v)));
+}
+
 template <typename WT, typename OT, int CH, int U>
 __global__ __launch_bounds__(256) void decode_fwd_kernel(const int64_t* __restrict__ idx, const void* __restrict__ v,
                                                          int v_dtype, const float* __restrict__ post_enc,
                                                          const float* __restrict__ post_scale,
-                                                         const WT* __restrict__ W, int d,
-                                                         const float* __restrict__ bias, OT* out, int flags,
-                                                         float* __restrict__ acts_out, int64_t N, int k) {
+                                                         const WT* __restrict__ W, int64_t M, int64_t lat_begin,
+                                                         int d, const float* __restrict__ bias, OT* out,
+                                                         int flags, float* __restrict__ acts_out, int64_t N,
+                                                         int k) {
   constexpr int E = Chunk<WT>::E;
   const int lane = threadIdx.x & 63;
   const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -86,15 +109,28 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(const int64_t* __restri
     const int j = j0 + lane;
     int my_r = 0;
     float my_a = 0.f;
+    bool valid = false;
     if (j < k) {
-      my_r = (int)idx[n * k + j];
-      float vv = load_scalar(v, v_dtype, n * k + j);
-      float a = post_affine(vv, my_r, post_enc, post_scale);
-      if (flags & CLT_DECODE_ROUND_ACTS) a = bf16_bits_to_f32(f32_to_bf16_bits(a));
+      const int64_t rr = idx[n * k + j] - lat_begin;
+      valid = rr >= 0 && rr < M;
+      my_r = valid ? (int)rr : 0;
+      float a = 0.f;
+      if (valid) {
+        const float vv = load_scalar(v, v_dtype, n * k + j);
+        a = post_affine(vv, my_r, post_enc, post_scale);
+        if (flags & CLT_DECODE_ROUND_ACTS) a = bf16_bits_to_f32(f32_to_bf16_bits(a));
+      }
       my_a = a;
       if (acts_out) acts_out[n * k + j] = a;
     }
-    const int cnt = min(64, k - j0);
+    int cnt = min(64, k - j0);
+    if (__ballot(valid) != __ballot(j < k)) {  // some entries belong to other shards: compact
+      int nv;
+      const int dest = compact_dest(valid, j < k, nv);
+      my_r = permute_push_i(dest, my_r);
+      my_a = permute_push_f(dest, my_a);
+      cnt = nv;
+    }
     for (int jj = 0; jj < cnt; jj += U) {
       uint4 raw[U][CH];
       float a_u[U];
@@ -151,8 +187,9 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(const int64_t* __restri
 template <typename WT, typename GT, int CH, int U>
 __global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
     const int64_t* __restrict__ idx, const void* __restrict__ v, int v_dtype, const float* __restrict__ post_enc,
-    const float* __restrict__ post_scale, const WT* __restrict__ W, int d, const GT* __restrict__ G,
-    float* grad_acts, int accumulate, float* __restrict__ e_post, float* __restrict__ e_scale, int64_t N, int k) {
+    const float* __restrict__ post_scale, const WT* __restrict__ W, int64_t M, int64_t lat_begin, int d,
+    const GT* __restrict__ G, float* grad_acts, int accumulate, float* __restrict__ e_post,
+    float* __restrict__ e_scale, int64_t N, int k) {
   constexpr int E = Chunk<WT>::E;
   const int lane = threadIdx.x & 63;
   const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -174,9 +211,23 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
   for (int j0 = 0; j0 < k; j0 += 64) {
     const int j = j0 + lane;
     int my_r = 0;
-    if (j < k) my_r = (int)idx[n * k + j];
+    bool valid = false;
+    if (j < k) {
+      const int64_t rr = idx[n * k + j] - lat_begin;
+      valid = rr >= 0 && rr < M;
+      my_r = valid ? (int)rr : 0;
+    }
+    int my_j = j;  // the entry this lane reports on (changes under compaction)
+    int cnt = min(64, k - j0);
+    if (__ballot(valid) != __ballot(j < k)) {
+      int nv;
+      const int dest = compact_dest(valid, j < k, nv);
+      my_r = permute_push_i(dest, my_r);
+      my_j = permute_push_i(dest, j);
+      valid = lane < nv;
+      cnt = nv;
+    }
     float my_ga = 0.f;
-    const int cnt = min(64, k - j0);
     for (int jj = 0; jj < cnt; jj += U) {
       uint4 raw[U][CH];
 #pragma unroll
@@ -207,14 +258,23 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
         if (jj + u < cnt && lane == jj + u) my_ga = part;
       }
     }
-    if (j < k) {
-      const int64_t o = n * k + j;
-      const float vv = load_scalar(v, v_dtype, o);
-      const float pos = vv > 0.f ? 1.f : 0.f;
-      const float u_ = post_scale ? my_ga * post_scale[my_r] : my_ga;
-      if (e_scale) e_scale[o] = my_ga * (vv + (post_enc ? post_enc[my_r] * pos : 0.f));
-      if (e_post) e_post[o] = u_ * pos;
-      grad_acts[o] = accumulate ? grad_acts[o] + u_ : u_;
+    if (my_j < k) {  // every entry of the chunk is reported by exactly one lane
+      const int64_t o = n * k + my_j;
+      float u_ = 0.f, es = 0.f, ep = 0.f;
+      if (valid) {
+        const float vv = load_scalar(v, v_dtype, o);
+        const float pos = vv > 0.f ? 1.f : 0.f;
+        u_ = post_scale ? my_ga * post_scale[my_r] : my_ga;
+        es = my_ga * (vv + (post_enc ? post_enc[my_r] * pos : 0.f));
+        ep = u_ * pos;
+      }
+      if (e_scale) e_scale[o] = es;
+      if (e_post) e_post[o] = ep;
+      if (accumulate) {
+        if (valid) grad_acts[o] += u_;
+      } else {
+        grad_acts[o] = u_;
+      }
     }
   }
 }
@@ -236,11 +296,11 @@ using namespace clt;
 
 template <typename WT, typename OT>
 static int launch_decode_fwd(int ch, dim3 grid, hipStream_t st, const int64_t* idx, const void* v, int v_dtype,
-                             const float* pe, const float* ps, const void* W, int d, const float* bias, void* out,
-                             int flags, float* acts_out, int64_t N, int k) {
+                             const float* pe, const float* ps, const void* W, int64_t M, int64_t lat_begin, int d,
+                             const float* bias, void* out, int flags, float* acts_out, int64_t N, int k) {
 #define LAUNCH(CH, U)                                                                                            \
   hipLaunchKernelGGL((decode_fwd_kernel<WT, OT, CH, U>), grid, dim3(256), 0, st, idx, v, v_dtype, pe, ps,        \
-                     (const WT*)W, d, bias, (OT*)out, flags, acts_out, N, k)
+                     (const WT*)W, M, lat_begin, d, bias, (OT*)out, flags, acts_out, N, k)
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
     case 2: LAUNCH(2, 8); break;
@@ -254,7 +314,7 @@ static int launch_decode_fwd(int ch, dim3 grid, hipStream_t st, const int64_t* i
 }
 
 extern "C" int clt_decode_fwd(const int64_t* idx, const void* v, int v_dtype, const float* post_enc,
-                              const float* post_scale, const void* W, int w_dtype, int64_t M, int d,
+                              const float* post_scale, const void* W, int w_dtype, int64_t M, int64_t lat_begin, int d,
                               const float* bias, void* out, int out_dtype, int flags, float* acts_out, int64_t N,
                               int k, clt_stream_t stream) {
   CLT_CHECK_ARG(idx && v && W && out, "clt_decode_fwd: null pointer");
@@ -272,13 +332,13 @@ extern "C" int clt_decode_fwd(const int64_t* idx, const void* v, int v_dtype, co
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (w_dtype == CLT_BF16 && out_dtype == CLT_BF16)
-    rc = launch_decode_fwd<bf16_t, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, bias, out, flags, acts_out, N, k);
+    rc = launch_decode_fwd<bf16_t, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, bias, out, flags, acts_out, N, k);
   else if (w_dtype == CLT_BF16 && out_dtype == CLT_F32)
-    rc = launch_decode_fwd<bf16_t, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, bias, out, flags, acts_out, N, k);
+    rc = launch_decode_fwd<bf16_t, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, bias, out, flags, acts_out, N, k);
   else if (w_dtype == CLT_F32 && out_dtype == CLT_F32)
-    rc = launch_decode_fwd<float, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, bias, out, flags, acts_out, N, k);
+    rc = launch_decode_fwd<float, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, bias, out, flags, acts_out, N, k);
   else
-    rc = launch_decode_fwd<float, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, bias, out, flags, acts_out, N, k);
+    rc = launch_decode_fwd<float, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, bias, out, flags, acts_out, N, k);
   if (rc != CLT_OK) {
     set_error("clt_decode_fwd: unsupported width d=%d", d);
     return rc;
@@ -289,11 +349,12 @@ extern "C" int clt_decode_fwd(const int64_t* idx, const void* v, int v_dtype, co
 
 template <typename WT, typename GT>
 static int launch_decode_bwd(int ch, dim3 grid, hipStream_t st, const int64_t* idx, const void* v, int v_dtype,
-                             const float* pe, const float* ps, const void* W, int d, const void* G, float* ga,
-                             int accumulate, float* e_post, float* e_scale, int64_t N, int k) {
+                             const float* pe, const float* ps, const void* W, int64_t M, int64_t lat_begin, int d,
+                             const void* G, float* ga, int accumulate, float* e_post, float* e_scale, int64_t N,
+                             int k) {
 #define LAUNCH(CH, U)                                                                                            \
   hipLaunchKernelGGL((decode_bwd_acts_kernel<WT, GT, CH, U>), grid, dim3(256), 0, st, idx, v, v_dtype, pe, ps,   \
-                     (const WT*)W, d, (const GT*)G, ga, accumulate, e_post, e_scale, N, k)
+                     (const WT*)W, M, lat_begin, d, (const GT*)G, ga, accumulate, e_post, e_scale, N, k)
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
     case 2: LAUNCH(2, 8); break;
@@ -307,8 +368,8 @@ static int launch_decode_bwd(int ch, dim3 grid, hipStream_t st, const int64_t* i
 }
 
 extern "C" int clt_decode_bwd_acts(const int64_t* idx, const void* v, int v_dtype, const float* post_enc,
-                                   const float* post_scale, const void* W, int w_dtype, int64_t M, int d,
-                                   const void* G, int g_dtype, float* grad_acts, int accumulate_grad_acts,
+                                   const float* post_scale, const void* W, int w_dtype, int64_t M, int64_t lat_begin,
+                                   int d, const void* G, int g_dtype, float* grad_acts, int accumulate_grad_acts,
                                    float* e_post, float* e_scale, int64_t N, int k, clt_stream_t stream) {
   CLT_CHECK_ARG(idx && v && W && G && grad_acts, "clt_decode_bwd_acts: null pointer");
   CLT_CHECK_ARG(N >= 0 && k > 0 && d > 0 && M > 0 && M < (1ll << 31), "clt_decode_bwd_acts: bad sizes");
@@ -325,13 +386,13 @@ extern "C" int clt_decode_bwd_acts(const int64_t* idx, const void* v, int v_dtyp
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (w_dtype == CLT_BF16 && g_dtype == CLT_BF16)
-    rc = launch_decode_bwd<bf16_t, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
+    rc = launch_decode_bwd<bf16_t, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
   else if (w_dtype == CLT_BF16 && g_dtype == CLT_F32)
-    rc = launch_decode_bwd<bf16_t, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
+    rc = launch_decode_bwd<bf16_t, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
   else if (w_dtype == CLT_F32 && g_dtype == CLT_F32)
-    rc = launch_decode_bwd<float, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
+    rc = launch_decode_bwd<float, float>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
   else
-    rc = launch_decode_bwd<float, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
+    rc = launch_decode_bwd<float, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, G, grad_acts, accumulate_grad_acts, e_post, e_scale, N, k);
   if (rc != CLT_OK) {
     set_error("clt_decode_bwd_acts: unsupported width d=%d", d);
     return rc;

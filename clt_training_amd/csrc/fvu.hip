@@ -45,6 +45,18 @@ __global__ __launch_bounds__(256) void fvu_colsum_kernel(const void* __restrict_
   }
 }
 
+__global__ void fvu_total_kernel(const float* __restrict__ psc, int NB, float* __restrict__ out2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float l2 = 0.f, tv = 0.f;
+    for (int b = 0; b < NB; ++b) {
+      l2 += psc[2 * b];
+      tv += psc[2 * b + 1];
+    }
+    out2[0] = l2;
+    out2[1] = tv;
+  }
+}
+
 __global__ void fvu_mean_kernel(const float* __restrict__ pcol, const float* __restrict__ pcnt, int NB, int d,
                                 float* __restrict__ mean) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,7 +65,7 @@ __global__ void fvu_mean_kernel(const float* __restrict__ pcol, const float* __r
   if (c < d) {
     float s = 0.f;
     for (int b = 0; b < NB; ++b) s += pcol[(int64_t)b * d + c];
-    mean[c] = s / cnt;
+    mean[c] = s;  // column SUM; the consumer divides by the (possibly all-reduced) count in mean[d]
   }
   if (c == 0) mean[d] = cnt;
 }
@@ -65,6 +77,7 @@ __global__ __launch_bounds__(256) void fvu_partial_kernel(const void* __restrict
                                                           float* __restrict__ psc) {
   __shared__ float red[2][4];
   const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(N, r0 + rpb);
+  const float inv_cnt = 1.f / mean[d];
   float l2 = 0.f, tv = 0.f;
   for (int64_t r = r0; r < r1; ++r) {
     const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(256) void fvu_partial_kernel(const void* __restrict
     for (int c = threadIdx.x; c < d; c += 256) {
       const float yy = ld(y, y_dtype, r * d + c);
       const float e = yy - ld(yhat, yh_dtype, r * d + c);
-      const float dv = yy - mean[c];
+      const float dv = yy - mean[c] * inv_cnt;
       l2 = fmaf(e, e, l2);
       tv = fmaf(dv, dv, tv);
     }
@@ -97,8 +110,12 @@ __global__ __launch_bounds__(256) void fvu_grad_kernel(const void* __restrict__ 
                                                        const uint8_t* __restrict__ mask, int64_t N, int d,
                                                        const float* __restrict__ psc, int NB, float gscale,
                                                        float* __restrict__ out_scalars, GT* __restrict__ G) {
-  // every block re-derives the totals in the same fixed order
+  // every block re-derives the totals in the same fixed order (NB == 0: psc already holds the totals)
   float l2 = 0.f, tv = 0.f;
+  if (NB == 0) {
+    l2 = psc[0];
+    tv = psc[1];
+  }
   for (int b = 0; b < NB; ++b) {
     l2 += psc[2 * b];
     tv += psc[2 * b + 1];
@@ -173,5 +190,67 @@ extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int
     hipLaunchKernelGGL((fvu_grad_kernel<float>), dim3(gb), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d,
                        (const float*)psc, NB, gscale, out_scalars, (float*)G);
   CLT_CHECK_LAUNCH("clt_fvu_fwd_bwd");
+  return CLT_OK;
+}
+
+// ---- the same three stages as separate entry points, for token-sharded (multi-GPU) FVU: the caller all-reduces
+//      colsum_count[d+1] after stage 1 and l2tv[2] after stage 2 (sparse_coder.py:214-221 under DTensor).
+extern "C" int clt_fvu_colsum(const void* y, int y_dtype, const uint8_t* mask, int64_t N, int d, float* colsum_count,
+                              void* workspace, size_t workspace_bytes, clt_stream_t stream) {
+  CLT_CHECK_ARG(y && colsum_count && workspace && N > 0 && d > 0 && valid_dtype(y_dtype), "clt_fvu_colsum: bad argument");
+  if (workspace_bytes < clt_fvu_workspace_bytes(N, d)) {
+    set_error("clt_fvu_colsum: workspace too small");
+    return CLT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int NB = fvu_blocks(N);
+  const int64_t rpb = (N + NB - 1) / NB;
+  float* pcol = reinterpret_cast<float*>(workspace);
+  float* pcnt = pcol + (size_t)NB * d;
+  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
+  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
+                     d, colsum_count);
+  CLT_CHECK_LAUNCH("clt_fvu_colsum");
+  return CLT_OK;
+}
+
+extern "C" int clt_fvu_partial(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask,
+                               int64_t N, int d, const float* colsum_count, float* l2tv, void* workspace,
+                               size_t workspace_bytes, clt_stream_t stream) {
+  CLT_CHECK_ARG(y && yhat && colsum_count && l2tv && workspace && N > 0 && d > 0, "clt_fvu_partial: bad argument");
+  CLT_CHECK_ARG(valid_dtype(y_dtype) && valid_dtype(yhat_dtype), "clt_fvu_partial: bad dtype");
+  if (workspace_bytes < clt_fvu_workspace_bytes(N, d)) {
+    set_error("clt_fvu_partial: workspace too small");
+    return CLT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int NB = fvu_blocks(N);
+  const int64_t rpb = (N + NB - 1) / NB;
+  float* psc = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(fvu_partial_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d, rpb,
+                     colsum_count, psc);
+  hipLaunchKernelGGL(fvu_total_kernel, dim3(1), dim3(64), 0, st, (const float*)psc, NB, l2tv);
+  CLT_CHECK_LAUNCH("clt_fvu_partial");
+  return CLT_OK;
+}
+
+extern "C" int clt_fvu_grad(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask, int64_t N,
+                            int d, const float* l2tv, float gscale, float* out_scalars, void* G, int g_dtype,
+                            clt_stream_t stream) {
+  CLT_CHECK_ARG(y && yhat && l2tv && out_scalars && G && N > 0 && d > 0, "clt_fvu_grad: bad argument");
+  CLT_CHECK_ARG(valid_dtype(y_dtype) && valid_dtype(yhat_dtype) && valid_dtype(g_dtype), "clt_fvu_grad: bad dtype");
+  CLT_UNSUPPORTED(d % 4 == 0, "clt_fvu_grad: d=%d must be a multiple of 4", d);
+  CLT_CHECK_ARG(aligned16(G), "clt_fvu_grad: G must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = N * (int64_t)d;
+  int64_t gb64 = (total + 1023) / 1024;
+  int gb = gb64 > 2048 ? 2048 : (int)gb64;
+  if (g_dtype == CLT_BF16)
+    hipLaunchKernelGGL((fvu_grad_kernel<bf16_t>), dim3(gb), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d,
+                       l2tv, 0, gscale, out_scalars, (bf16_t*)G);
+  else
+    hipLaunchKernelGGL((fvu_grad_kernel<float>), dim3(gb), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d,
+                       l2tv, 0, gscale, out_scalars, (float*)G);
+  CLT_CHECK_LAUNCH("clt_fvu_grad");
   return CLT_OK;
 }

@@ -17,11 +17,13 @@
 
 namespace clt {
 
+// key = latent - lat_begin, or the sentinel M for entries of other shards (sorted behind every real segment)
 __global__ void seg_prepare_kernel(const int64_t* __restrict__ idx, int32_t* __restrict__ keys,
-                                   int32_t* __restrict__ ids, int64_t n) {
+                                   int32_t* __restrict__ ids, int64_t n, int64_t M, int64_t lat_begin) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    keys[i] = (int32_t)idx[i];
+    const int64_t r = idx[i] - lat_begin;
+    keys[i] = (r >= 0 && r < M) ? (int32_t)r : (int32_t)M;
     ids[i] = (int32_t)i;
   }
 }
@@ -144,7 +146,7 @@ __global__ void segment_sum_kernel(const int32_t* __restrict__ perm, const int32
 
 static int key_bits(int64_t M) {
   int bits = 1;
-  while ((1ll << bits) < M) ++bits;
+  while ((1ll << bits) < M + 1) ++bits;  // + the sentinel key M
   return bits;
 }
 
@@ -165,7 +167,8 @@ extern "C" size_t clt_segments_workspace_bytes(int64_t n_entries, int64_t M) {
   return 3 * a + align_up(sort_temp_bytes(n_entries, M), 256) + 256;
 }
 
-extern "C" int clt_segments_build(const int64_t* idx, int64_t n, int64_t M, int32_t* perm, int32_t* offsets,
+extern "C" int clt_segments_build(const int64_t* idx, int64_t n, int64_t M, int64_t lat_begin, int32_t* perm,
+                                  int32_t* offsets,
                                   void* workspace, size_t workspace_bytes, clt_stream_t stream) {
   CLT_CHECK_ARG(idx && perm && offsets && workspace, "clt_segments_build: null pointer");
   CLT_CHECK_ARG(n > 0 && n < (1ll << 31) && M > 0 && M < (1ll << 31), "clt_segments_build: bad sizes n=%lld M=%lld",
@@ -184,7 +187,7 @@ extern "C" int clt_segments_build(const int64_t* idx, int64_t n, int64_t M, int3
   void* temp = ws + 3 * a;
   size_t temp_bytes = sort_temp_bytes(n, M);
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(seg_prepare_kernel, dim3(blocks), dim3(256), 0, st, idx, keys_in, ids_in, n);
+  hipLaunchKernelGGL(seg_prepare_kernel, dim3(blocks), dim3(256), 0, st, idx, keys_in, ids_in, n, M, lat_begin);
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int32_t*)keys_in, keys_out,
                                            (const int32_t*)ids_in, perm, (size_t)n, 0, key_bits(M), st, false);
   if (e != hipSuccess) {

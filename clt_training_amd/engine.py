@@ -1,0 +1,362 @@
+"""Explicit (autograd-free) CLT train-step engine with latent sharding over RCCL.
+
+This is the MI355X replacement for the reference's DTensor tensor parallelism
+(sparsify/fused_encoder.py:339-370, sparsify/utils.py:479-546, sparsify/trainer.py:526-539):
+
+  * rank r of the ``tp`` group owns latents [r*M/tp, (r+1)*M/tp): rows of ``W_enc`` / ``b_enc``, rows of
+    every ``W_decs[t]``, slices of ``post_encs`` / ``post_enc_scales`` and their Adam state;
+    ``b_decs`` / ``W_skips`` / ``in_norm`` / ``out_norm`` are replicated;
+  * every rank brings its own N_r tokens; the encoder inputs are all-gathered over tp
+    (trainer.py:535) so that the group encodes N = tp * N_r tokens;
+  * local GEMM + top-k on [N, M/tp], ONE all-gather each of the candidate values and global indices,
+    and the same deterministic merge top-k on every rank (fused_encoder.py:347-360);
+  * each rank decodes only the selected latents it owns (compacted, not masked) into a full-width
+    partial sum over ALL live source layers of a target, then ONE reduce-scatter per target layer
+    leaves every rank with the reconstruction of its own tokens (the ``tp_output=False`` /
+    ``Partial("sum")`` layout of utils.py:518-530);
+  * FVU on token shards with two small all-reduces (column sums + count, then (l2, tv));
+  * backward: the loss gradient of the local tokens is all-gathered once per target; everything a rank
+    needs for its own latents is then local (no all-reduce of activation gradients: every (token, slot)
+    entry is owned by exactly one rank); only the replicated ``b_decs`` / ``W_skips`` gradients are
+    all-reduced, once per step, in one flat bucket.
+
+With tp == 1 every collective is the identity and the engine is the single-GPU fast path: the same
+arithmetic as CrossLayerRunner + autograd (``coalesce_topk="none"``), without the autograd graph.
+
+The arithmetic backend is injected (``ops``): the product passes ``clt_training_amd.hip_ops`` (HIP kernels,
+no CPU fallback); the CPU tests pass an oracle-backed double to exercise the sharding / collective logic
+under gloo.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from .config import SparseCoderConfig, TrainConfig
+
+
+# --------------------------------------------------------------------------- collectives
+class Comm:
+    """Thin wrapper over one torch.distributed group (backend "nccl" = RCCL on ROCm; gloo in CPU tests)."""
+
+    def __init__(self, group=None, enabled: Optional[bool] = None):
+        self.enabled = dist.is_available() and dist.is_initialized() if enabled is None else enabled
+        self.group = group
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        self.backend = dist.get_backend(group) if self.enabled else "none"
+
+    def all_gather_rows(self, t: Tensor) -> Tensor:
+        """[n, ...] per rank -> [world * n, ...] (rank-major)."""
+        if self.world == 1:
+            return t
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+    def all_gather_cat1(self, t: Tensor) -> Tensor:
+        """[N, k] per rank -> [N, world * k] (candidates of every shard side by side)."""
+        if self.world == 1:
+            return t
+        g = self.all_gather_rows(t)  # [world * N, k]
+        N, k = t.shape
+        return g.view(self.world, N, k).permute(1, 0, 2).reshape(N, self.world * k).contiguous()
+
+    def reduce_scatter_rows(self, t: Tensor) -> Tensor:
+        """sum over ranks of [world * n, d], rank r keeps rows [r*n, (r+1)*n)."""
+        if self.world == 1:
+            return t
+        t = t.contiguous()
+        n = t.shape[0] // self.world
+        if self.backend == "gloo":  # gloo has no reduce_scatter: all-reduce and slice (CPU tests only)
+            dist.all_reduce(t, group=self.group)
+            return t[self.rank * n:(self.rank + 1) * n].clone()
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.reduce_scatter_tensor(out, t, group=self.group)
+        return out
+
+    def all_reduce_(self, t: Tensor) -> Tensor:
+        if self.world > 1:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+
+# --------------------------------------------------------------------------- sharded parameters
+class ShardedCoder(nn.Module):
+    """The parameters of one SparseCoder (sparse_coder.py:233-445) with the latent dimension sharded.
+    Names follow the reference's state dict; ``W_decs`` etc. always are lists (one entry per target slot,
+    a single entry for a plain SAE / transcoder)."""
+
+    def __init__(self, d_in: int, cfg: SparseCoderConfig, device, rank: int = 0, tp: int = 1,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__()
+        if cfg.coalesce_topk != "none" or cfg.per_source_tied or cfg.secondary_target_tied:
+            raise NotImplementedError("the sharded engine implements coalesce_topk='none'")
+        self.cfg, self.d_in, self.rank, self.tp = cfg, d_in, rank, tp
+        self.num_latents = cfg.num_latents or d_in * cfg.expansion_factor
+        assert self.num_latents % tp == 0, "latents must divide evenly over the tp ranks"
+        self.m_local = self.num_latents // tp
+        self.lat_begin = rank * self.m_local
+        self.n_slots = max(1, cfg.n_targets if cfg.transcode else 1)
+        wd = cfg.torch_dtype or dtype
+        Ml, T = self.m_local, self.n_slots
+        scaling = 1.0 / d_in**0.5  # nn.Linear default init == U(-1/sqrt(d), 1/sqrt(d)) (sparse_coder.py:271-284)
+        w = (torch.rand(Ml, d_in, device=device, dtype=torch.float32) * (2.0 * scaling) - scaling).to(wd)
+        self.W_enc = nn.Parameter(w)
+        self.b_enc = nn.Parameter(torch.zeros(Ml, device=device, dtype=wd))
+        if cfg.transcode:
+            self.W_decs = nn.ParameterList([nn.Parameter(torch.zeros(Ml, d_in, device=device, dtype=wd)) for _ in range(T)])
+        else:
+            wdec = w.float()
+            if cfg.normalize_decoder:
+                wdec = wdec / (wdec.norm(dim=1, keepdim=True) + torch.finfo(wd).eps)
+            self.W_decs = nn.ParameterList([nn.Parameter(wdec.to(wd))])
+        self.b_decs = nn.ParameterList([nn.Parameter(torch.zeros(d_in, device=device, dtype=dtype)) for _ in range(T)])
+        self.W_skips = nn.ParameterList(
+            [nn.Parameter(torch.zeros(d_in, d_in, device=device, dtype=dtype)) for _ in range(T)]
+        ) if cfg.skip_connection else None
+        self.post_encs = nn.ParameterList(
+            [nn.Parameter(torch.zeros(Ml, device=device, dtype=dtype), requires_grad=cfg.train_post_encoder)
+             for _ in range(T)])
+        self.post_enc_scales = nn.ParameterList(
+            [nn.Parameter((torch.ones if i == 0 else torch.zeros)(Ml, device=device, dtype=dtype),
+                          requires_grad=cfg.train_post_encoder) for i in range(T)]
+        ) if cfg.post_encoder_scale else None
+        if cfg.normalize_io:
+            self.register_buffer("in_norm", torch.ones(1, device=device, dtype=dtype))
+            self.register_buffer("out_norm", torch.ones(1, device=device, dtype=dtype))
+
+    @staticmethod
+    def from_full(sae, rank: int, tp: int, device=None) -> "ShardedCoder":
+        """Slice an unsharded ``SparseCoder`` (used by parity tests and for loading checkpoints)."""
+        device = device or sae.device
+        sc = ShardedCoder(sae.d_in, sae.cfg, device, rank, tp, dtype=torch.float32)
+        lo, hi = sc.lat_begin, sc.lat_begin + sc.m_local
+        T = sc.n_slots
+        multi = hasattr(sae, "W_decs")
+
+        def slot(plural, single, i):
+            return getattr(sae, plural)[i] if hasattr(sae, plural) else getattr(sae, single)
+
+        with torch.no_grad():
+            sc.W_enc.data = sae.encoder.weight.data[lo:hi].clone().to(device)
+            sc.b_enc.data = sae.encoder.bias.data[lo:hi].clone().to(device)
+            for i in range(T):
+                sc.W_decs[i].data = slot("W_decs", "W_dec", i).data[lo:hi].clone().to(device)
+                sc.b_decs[i].data = slot("b_decs", "b_dec", i).data.clone().to(device)
+                if sc.W_skips is not None:
+                    sc.W_skips[i].data = slot("W_skips", "W_skip", i).data.clone().to(device)
+                sc.post_encs[i].data = slot("post_encs", "post_enc", i).data[lo:hi].clone().to(device)
+                if sc.post_enc_scales is not None:
+                    sc.post_enc_scales[i].data = slot("post_enc_scales", "post_enc_scale", i).data[lo:hi].clone().to(device)
+            if sae.cfg.normalize_io:
+                sc.in_norm.copy_(sae.in_norm)
+                sc.out_norm.copy_(sae.out_norm)
+        del multi
+        return sc
+
+    def replicated_parameters(self):
+        out = list(self.b_decs)
+        if self.W_skips is not None:
+            out += list(self.W_skips)
+        return out
+
+
+@dataclass
+class _Live:
+    """One live source layer (the engine's MidDecoder, sparse_coder.py:39-101)."""
+
+    layer: int
+    xn_r: Tensor            # normalised input of the LOCAL tokens (skip connection)
+    x_enc: Tensor           # encoder input of ALL tokens of the group (encoder backward)
+    v: Tensor               # merged top-k values [N, k]
+    idx: Tensor             # merged top-k global indices [N, k] int64
+    gv: Tensor              # accumulated grad wrt v [N, k] fp32 (the detached leaf's .grad)
+    slot: int = 0
+    seg: object = None
+    acts: dict = field(default_factory=dict)
+
+
+class CLTEngine:
+    """One FVU train step over all layers (trainer.py:598-682, 791-816), explicit forward and backward."""
+
+    def __init__(self, cfg: TrainConfig, coders: list, ops, comm: Optional[Comm] = None):
+        self.cfg, self.coders, self.ops = cfg, coders, ops
+        self.comm = comm or Comm(enabled=False)
+        self.live: list[_Live] = []
+        self.last_fvu = {}
+
+    # ---- helpers
+    def _cd(self, lp: ShardedCoder):
+        return lp.W_enc.dtype
+
+    def reset(self):
+        self.live = []
+
+    @torch.no_grad()
+    def first_step_init(self, j: int, x_r: Tensor, y_r: Tensor):
+        """trainer.py:547-592 on token shards: the means / norms are all-reduced over the group."""
+        lp, comm = self.coders[j], self.comm
+        d = x_r.shape[-1]
+        n = torch.tensor([float(x_r.shape[0])], device=x_r.device)
+        comm.all_reduce_(n)
+        if lp.cfg.transcode:
+            s = x_r.float().sum(0)
+            comm.all_reduce_(s)
+            mean = -(s / n).to(lp.W_enc.dtype)
+            lp.b_enc.data[:] = torch.nn.functional.linear(mean, lp.W_enc.data)
+        s = y_r.float().sum(0)
+        comm.all_reduce_(s)
+        lp.b_decs[0].data[:] = (s / n).to(lp.b_decs[0].dtype)
+        if lp.cfg.normalize_io:
+            nx = x_r.float().norm(dim=-1).sum()
+            ny = y_r.float().norm(dim=-1).sum()
+            comm.all_reduce_(nx)
+            comm.all_reduce_(ny)
+            in_norm, out_norm = nx / n, ny / n
+            lp.in_norm.data[:] = in_norm
+            lp.out_norm.data[:] = out_norm
+            for b in lp.b_decs:
+                b.data[:] = b.data * (d**0.5 / out_norm)
+            lp.b_enc.data[:] = (lp.b_enc.data.float() * (d**0.5 / in_norm)).to(lp.b_enc.dtype)
+
+    # ---- one hook call (trainer.py:492-682)
+    @torch.no_grad()
+    def layer_step(self, j: int, x_r: Tensor, y_r: Tensor, mask_r: Optional[Tensor], acc_steps: int = 1) -> Tensor:
+        ops, comm = self.ops, self.comm
+        lp = self.coders[j]
+        cfg = lp.cfg
+        cd = self._cd(lp)
+        d, k = lp.d_in, cfg.k
+        Ml, lat0 = lp.m_local, lp.lat_begin
+        if not cfg.transcode:
+            x_r = y_r
+        # ---------------- encode (sparse_coder.py:632-647, fused_encoder.py:293-372)
+        xn_r = x_r.float() * (d**0.5 / lp.in_norm) if cfg.normalize_io else x_r
+        x_enc_r = xn_r if cfg.transcode else xn_r.float() - lp.b_decs[0]
+        x_enc = comm.all_gather_rows(x_enc_r.to(cd))
+        v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, k, out_dtype=cd)
+        if comm.world > 1:
+            cand_v = comm.all_gather_cat1(v)
+            cand_i = comm.all_gather_cat1(idx + lat0)
+            v, idx = ops.topk_rows(cand_v, k, cand_idx=cand_i)
+        N = x_enc.shape[0]
+        me = _Live(j, xn_r.to(cd), x_enc, v, idx, torch.zeros(N, k, dtype=torch.float32, device=v.device))
+        self.live.append(me)
+        div = max(1, len(self.live) - 1) if cfg.divide_cross_layer else 1  # runner.py:46-49
+
+        # ---------------- forward: partial decode of every live source into this target
+        P_cur = P_oth = None
+        E_cur = E_oth = None
+        for st in self.live:
+            li = self.coders[st.layer]
+            t = st.slot
+            ps = li.post_enc_scales[t] if li.post_enc_scales is not None else None
+            is_cur = st is me
+            acc_into = None if is_cur else P_oth
+            out, acts = ops.decode_fwd(st.idx, st.v, li.W_decs[t], post_enc=li.post_encs[t], post_scale=ps,
+                                       round_acts=li.W_decs[t].dtype == torch.bfloat16, want_acts=True,
+                                       lat_begin=li.lat_begin, out=acc_into, accumulate=acc_into is not None)
+            st.acts[t] = acts
+            extra = li.b_decs[t].float().unsqueeze(0)
+            if li.W_skips is not None:
+                extra = extra + (st.xn_r @ li.W_skips[t].to(cd).mT).float()  # sparse_coder.py:190
+            if is_cur:
+                P_cur, E_cur = out, extra
+            else:
+                P_oth = out
+                E_oth = extra if E_oth is None else E_oth + extra
+        P = P_cur if P_oth is None else (P_cur + P_oth if div == 1 else P_cur + P_oth / div)
+        E = E_cur if E_oth is None else (E_cur + E_oth if div == 1 else E_cur + E_oth / div)
+        yhat_r = comm.reduce_scatter_rows(P).float() + E
+        denorm = (lp.out_norm / d**0.5) if cfg.normalize_io else None  # sparse_coder.py:627-630
+        if denorm is not None:
+            yhat_r = yhat_r * denorm
+
+        # ---------------- FVU on token shards (sparse_coder.py:207-221)
+        colsum = comm.all_reduce_(ops.fvu_colsum(y_r, mask_r))
+        l2tv = comm.all_reduce_(ops.fvu_partial(y_r, yhat_r, mask_r, colsum))
+        sc, G_r = ops.fvu_grad(y_r, yhat_r, mask_r, l2tv, gscale=1.0 / acc_steps, g_dtype=cd)
+        fvu = sc[0]
+
+        # ---------------- backward
+        if denorm is not None:
+            G_r = (G_r.float() * denorm).to(cd)
+        G = comm.all_gather_rows(G_r)
+        G_div = G if div == 1 else (G.float() / div).to(cd)
+        G_r_div = G_r if div == 1 else (G_r.float() / div).to(cd)
+        for st in self.live:
+            li = self.coders[st.layer]
+            t = st.slot
+            is_cur = st is me
+            Gi, Gi_r = (G, G_r) if is_cur else (G_div, G_r_div)
+            self._acc_grad(li.b_decs[t], Gi_r.sum(0, dtype=torch.float32))
+            if li.W_skips is not None:
+                self._acc_grad(li.W_skips[t], (Gi_r.mT @ st.xn_r).float())
+            ps = li.post_enc_scales[t] if li.post_enc_scales is not None else None
+            need_pe = li.post_encs[t].requires_grad
+            _, e_post, e_scale = ops.decode_bwd_acts(st.idx, st.v, li.W_decs[t], Gi, post_enc=li.post_encs[t],
+                                                     post_scale=ps, grad_acts=st.gv, want_e_post=need_pe,
+                                                     lat_begin=li.lat_begin)
+            if st.seg is None:
+                st.seg = ops.segments_build(st.idx, li.m_local, lat_begin=li.lat_begin)
+            self._acc_grad(li.W_decs[t], ops.spt_dense(st.seg, st.acts.pop(t).view(-1), Gi, out_dtype=li.W_decs[t].dtype))
+            if need_pe:
+                if ps is not None and ps.requires_grad:
+                    gp, gs = ops.segment_sum(st.seg, e_post.view(-1), e_scale.view(-1))
+                    self._acc_grad(ps, gs)
+                else:
+                    gp, _ = ops.segment_sum(st.seg, e_post.view(-1))
+                self._acc_grad(li.post_encs[t], gp)
+
+        # ---------------- advance; deferred encoder backward (runner.py:56-59,193-197; fused_encoder.py:92-155)
+        still = []
+        for st in self.live:
+            li = self.coders[st.layer]
+            st.slot += 1
+            if st.slot >= li.n_slots:
+                gW, gb = ops.spt_dense(st.seg, st.gv.view(-1), st.x_enc, gate=st.v.contiguous().view(-1),
+                                       out_dtype=li.W_enc.dtype, want_rowsum=True)
+                self._acc_grad(li.W_enc, gW)
+                self._acc_grad(li.b_enc, gb.to(li.b_enc.dtype))
+                if not li.cfg.transcode:
+                    # SAE: the encoder input is xn - b_dec (sparse_coder.py:637-638): b_dec also gets -sum_n grad_x
+                    gated = st.gv * (st.v > 0)
+                    gx = ops.decode_fwd(st.idx, gated, li.W_enc, lat_begin=li.lat_begin, out_dtype=torch.float32)
+                    self._acc_grad(li.b_decs[0], -gx.sum(0, dtype=torch.float32))
+            else:
+                still.append(st)
+        self.live = still
+        self.last_fvu[j] = fvu
+        return fvu
+
+    @staticmethod
+    def _acc_grad(p: Tensor, g: Tensor):
+        if g.dtype != p.dtype:
+            g = g.to(p.dtype)
+        if p.grad is None:
+            p.grad = g
+        else:
+            p.grad += g
+
+    @torch.no_grad()
+    def sync_replicated_grads(self):
+        """One flat all-reduce for the gradients of the replicated parameters (b_decs, W_skips)."""
+        if self.comm.world == 1:
+            return
+        grads = [p.grad for c in self.coders for p in c.replicated_parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1).float() for g in grads])
+        self.comm.all_reduce_(flat)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n

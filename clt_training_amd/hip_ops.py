@@ -145,7 +145,8 @@ def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=Non
 # ----------------------------------------------------------------------------- decoder
 def decode_fwd(idx: Tensor, v: Tensor, W: Tensor, *, post_enc: Optional[Tensor] = None,
                post_scale: Optional[Tensor] = None, bias: Optional[Tensor] = None, out: Optional[Tensor] = None,
-               out_dtype=None, accumulate: bool = False, round_acts: bool = False, want_acts: bool = False):
+               out_dtype=None, accumulate: bool = False, round_acts: bool = False, want_acts: bool = False,
+               lat_begin: int = 0):
     idx, v, W = _idx(idx), _c(v), _c(W)
     N, k = idx.shape
     M, d = W.shape
@@ -157,14 +158,14 @@ def decode_fwd(idx: Tensor, v: Tensor, W: Tensor, *, post_enc: Optional[Tensor] 
     flags = (CLT_DECODE_ACCUMULATE if accumulate else 0) | (CLT_DECODE_ROUND_ACTS if round_acts else 0)
     for t in (post_enc, post_scale, bias):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
-    _call("clt_decode_fwd", _ptr(idx), _ptr(v), _dt(v), _ptr(post_enc), _ptr(post_scale), _ptr(W), _dt(W), M, d,
+    _call("clt_decode_fwd", _ptr(idx), _ptr(v), _dt(v), _ptr(post_enc), _ptr(post_scale), _ptr(W), _dt(W), M, lat_begin, d,
                                      _ptr(bias), _ptr(out), _dt(out), flags, _ptr(acts), N, k, _stream(W))
     return (out, acts) if want_acts else out
 
 
 def decode_bwd_acts(idx: Tensor, v: Tensor, W: Tensor, G: Tensor, *, post_enc: Optional[Tensor] = None,
                     post_scale: Optional[Tensor] = None, grad_acts: Optional[Tensor] = None,
-                    want_e_post: bool = False):
+                    want_e_post: bool = False, lat_begin: int = 0):
     idx, v, W, G = _idx(idx), _c(v), _c(W), _c(G)
     N, k = idx.shape
     M, d = W.shape
@@ -174,7 +175,7 @@ def decode_bwd_acts(idx: Tensor, v: Tensor, W: Tensor, G: Tensor, *, post_enc: O
     e_post = torch.empty(N, k, dtype=torch.float32, device=W.device) if want_e_post else None
     e_scale = torch.empty(N, k, dtype=torch.float32, device=W.device) if post_scale is not None else None
     _call("clt_decode_bwd_acts", _ptr(idx), _ptr(v), _dt(v), _ptr(post_enc), _ptr(post_scale), _ptr(W), _dt(W),
-                                          M, d, _ptr(G), _dt(G), _ptr(grad_acts), int(accumulate), _ptr(e_post),
+                                          M, lat_begin, d, _ptr(G), _dt(G), _ptr(grad_acts), int(accumulate), _ptr(e_post),
                                           _ptr(e_scale), N, k, _stream(W))
     return grad_acts, e_post, e_scale
 
@@ -190,7 +191,7 @@ class Segments:
         self.perm, self.offsets, self.M, self.k = perm, offsets, M, k
 
 
-def segments_build(idx: Tensor, M: int) -> Segments:
+def segments_build(idx: Tensor, M: int, lat_begin: int = 0) -> Segments:
     idx = _idx(idx)
     n = idx.numel()
     lib = _lib.load()
@@ -198,7 +199,7 @@ def segments_build(idx: Tensor, M: int) -> Segments:
     offsets = torch.empty(M + 1, dtype=torch.int32, device=idx.device)
     nbytes = lib.clt_segments_workspace_bytes(n, M)
     ws = workspace(idx.device, nbytes, "seg")
-    _call("clt_segments_build", _ptr(idx), n, M, _ptr(perm), _ptr(offsets), _ptr(ws), ws.numel(), _stream(idx))
+    _call("clt_segments_build", _ptr(idx), n, M, lat_begin, _ptr(perm), _ptr(offsets), _ptr(ws), ws.numel(), _stream(idx))
     return Segments(perm, offsets, M, idx.shape[-1])
 
 
@@ -246,4 +247,45 @@ def fvu_fwd_bwd(y: Tensor, yhat: Tensor, mask: Optional[Tensor], gscale: float =
         mask = _c(mask.to(torch.bool)).view(torch.uint8)
     _call("clt_fvu_fwd_bwd", _ptr(y), _dt(y), _ptr(yhat), _dt(yhat), _ptr(mask), N, d, float(gscale), _ptr(sc), _ptr(G),
                               _DT[g_dtype], _ptr(ws), ws.numel(), _stream(y))
+    return sc, G
+
+
+def fvu_colsum(y: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """Stage 1 of the token-sharded FVU: local [sum_n m*y (d values), sum_n m]."""
+    y = _c(y)
+    N, d = y.shape
+    lib = _lib.load()
+    ws = workspace(y.device, lib.clt_fvu_workspace_bytes(N, d), "fvu")
+    out = torch.empty(d + 1, dtype=torch.float32, device=y.device)
+    if mask is not None:
+        mask = _c(mask.to(torch.bool)).view(torch.uint8)
+    _call("clt_fvu_colsum", _ptr(y), _dt(y), _ptr(mask), N, d, _ptr(out), _ptr(ws), ws.numel(), _stream(y))
+    return out
+
+
+def fvu_partial(y: Tensor, yhat: Tensor, mask: Optional[Tensor], colsum_count: Tensor) -> Tensor:
+    """Stage 2: local (l2, tv) given the global column sums / count."""
+    y, yhat = _c(y), _c(yhat)
+    N, d = y.shape
+    lib = _lib.load()
+    ws = workspace(y.device, lib.clt_fvu_workspace_bytes(N, d), "fvu")
+    out = torch.empty(2, dtype=torch.float32, device=y.device)
+    if mask is not None:
+        mask = _c(mask.to(torch.bool)).view(torch.uint8)
+    _call("clt_fvu_partial", _ptr(y), _dt(y), _ptr(yhat), _dt(yhat), _ptr(mask), N, d, _ptr(colsum_count), _ptr(out),
+          _ptr(ws), ws.numel(), _stream(y))
+    return out
+
+
+def fvu_grad(y: Tensor, yhat: Tensor, mask: Optional[Tensor], l2tv: Tensor, gscale: float = 1.0, g_dtype=None):
+    """Stage 3: scalars (fvu, l2, tv) and G = gscale * (-2 / tv) * m * (y - yhat) from the global (l2, tv)."""
+    y, yhat = _c(y), _c(yhat)
+    N, d = y.shape
+    g_dtype = g_dtype or yhat.dtype
+    sc = torch.empty(3, dtype=torch.float32, device=y.device)
+    G = torch.empty(N, d, dtype=g_dtype, device=y.device)
+    if mask is not None:
+        mask = _c(mask.to(torch.bool)).view(torch.uint8)
+    _call("clt_fvu_grad", _ptr(y), _dt(y), _ptr(yhat), _dt(yhat), _ptr(mask), N, d, _ptr(l2tv), float(gscale), _ptr(sc),
+          _ptr(G), _DT[g_dtype], _stream(y))
     return sc, G

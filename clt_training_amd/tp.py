@@ -1,0 +1,110 @@
+"""Latent-sharded trainer: ``TPTrainer`` drives ``CLTEngine`` over one ``torch.distributed`` group
+(one process per GPU; backend "nccl" is RCCL over xGMI on ROCm).  It keeps the reference Trainer's
+construction rule, Adam groups + LR rule, warm-up schedule, step-0 init and step order
+(sparsify/trainer.py:113-193, 547-592, 791-816); the mesh convention is (dp=1, tp=world)
+(sparsify/__main__.py:173-177)."""
+from __future__ import annotations
+
+from dataclasses import replace
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .adam import Adam
+from .config import TrainConfig
+from .engine import CLTEngine, Comm, ShardedCoder
+from .trainer import WarmupLinearSchedule
+
+
+class TPTrainer:
+    def __init__(self, cfg: TrainConfig, dataset, model=None, mesh=None, *, device="cuda",
+                 input_widths: Optional[dict] = None, num_batches: Optional[int] = None, ops=None, group=None,
+                 optimizer_cls=None, coders: Optional[list] = None):
+        assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
+        if cfg.optimizer != "adam" or cfg.loss_fn != "fvu":
+            raise NotImplementedError("only optimizer='adam', loss_fn='fvu' are on the MI355X hot path")
+        cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
+        self.cfg, self.dataset = cfg, dataset
+        self.device = torch.device(device)
+        self.comm = Comm(group)
+        if ops is None:
+            from . import hip_ops as ops  # the product path: HIP kernels, no CPU fallback
+        self.ops = ops
+        if input_widths is None:
+            first = next(iter(dataset))
+            input_widths = {h: first[h][0].shape[-1] for h in cfg.hookpoints}
+        self.saes = {}
+        if coders is None:
+            sources = []
+            for position, hook in enumerate(cfg.hookpoints):  # trainer.py:113-146
+                torch.manual_seed(cfg.init_seeds[0] + 1000003 * self.comm.rank)  # every shard draws its own rows
+                if cfg.cross_layer > 0:
+                    n_targets = min(cfg.cross_layer, len(cfg.hookpoints) - position)
+                    sources.append(position + n_targets)
+                    while sources[0] < position:
+                        sources.pop(0)
+                    n_sources = len(sources)
+                else:
+                    n_targets = n_sources = 0
+                sae_cfg = replace(cfg.sae, n_targets=n_targets, n_sources=n_sources)
+                self.saes[hook] = ShardedCoder(input_widths[hook], sae_cfg, self.device, self.comm.rank, self.comm.world)
+        else:
+            self.saes = dict(zip(cfg.hookpoints, coders))
+        self.engine = CLTEngine(cfg, [self.saes[h] for h in cfg.hookpoints], ops, self.comm)
+        if num_batches is None:
+            num_batches = len(dataset)
+        pgs = [dict(params=[p for p in sae.parameters() if p.requires_grad],
+                    lr=torch.tensor(cfg.lr or 2e-4 / (sae.num_latents / (2**14)) ** 0.5))
+               for sae in self.saes.values()]  # trainer.py:166-173: the FULL latent count sets the LR
+        adam = (optimizer_cls or Adam)(pgs, betas=(cfg.b1, cfg.b2))
+        self.optimizers = [adam]
+        self.lr_schedulers = [WarmupLinearSchedule(adam, cfg.lr_warmup_steps, num_batches)]
+        self.global_step = 0
+        self.num_tokens_since_fired = {h: torch.zeros(s.m_local, device=self.device, dtype=torch.long)
+                                       for h, s in self.saes.items()}
+        self.did_fire = {h: torch.zeros(s.m_local, device=self.device, dtype=torch.bool) for h, s in self.saes.items()}
+        self.num_tokens_in_step = 0
+        self.last_fvu = {}
+
+    @torch.no_grad()
+    def step(self, batch: dict):
+        cfg, eng = self.cfg, self.engine
+        acc_steps = cfg.grad_acc_steps * cfg.micro_acc_steps
+        eng.reset()
+        mask = batch.get("loss_mask")
+        n_tok = 0
+        for j, name in enumerate(cfg.hookpoints):
+            x, y = batch[name]
+            sae = self.saes[name]
+            n_tok = x.shape[0] * self.comm.world
+            if self.global_step == 0 and not cfg.finetune:
+                eng.first_step_init(j, x if cfg.sae.transcode else y, y)
+            if sae.cfg.normalize_decoder and not cfg.sae.transcode:  # trainer.py:595-596 (row-wise: shard-local)
+                W = sae.W_decs[0]
+                W.data /= W.data.norm(dim=1, keepdim=True) + torch.finfo(W.dtype).eps
+            n_live_before = len(eng.live)
+            self.last_fvu[name] = eng.layer_step(j, x, y, mask, acc_steps)
+            del n_live_before
+        self.num_tokens_in_step += n_tok
+        step, substep = divmod(self.global_step + 1, cfg.grad_acc_steps)
+        if substep == 0:
+            eng.sync_replicated_grads()
+            if cfg.sae.normalize_decoder and not cfg.sae.transcode:  # sparse_coder.py:696-711 (row-wise)
+                for sae in self.saes.values():
+                    W = sae.W_decs[0]
+                    W.grad -= (W.grad * W.data).sum(1, keepdim=True) * W.data
+            for opt in self.optimizers:
+                opt.step()
+                opt.zero_grad()
+            for sch in self.lr_schedulers:
+                sch.step()
+        self.global_step += 1
+        return self.last_fvu
+
+    def fit(self, log=None):
+        for batch in self.dataset:
+            fv = self.step(batch)
+            if log is not None:
+                log(self.global_step, fv)
+        return self

@@ -83,12 +83,16 @@ int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, const void* 
  *   a'[n,j] = (v[n,j] + post_enc[idx]*(v>0)) * post_scale[idx]      (either may be NULL)
  *   out[n,:] = (flags & CLT_DECODE_ACCUMULATE ? out[n,:] : 0) + bias + sum_j a'[n,j] * W[idx[n,j],:]
  * v [N,k] in `v_dtype`; W [M,d] in `w_dtype`; post_enc/post_scale/bias fp32;
- * out [N,d] in `out_dtype`; acts_out [N,k] fp32 or NULL receives a'.  fp32 accumulation. */
+ * out [N,d] in `out_dtype`; acts_out [N,k] fp32 or NULL receives a'.  fp32 accumulation.
+ * Latent sharding (replaces parallelize_decoder's mask-and-relocate, utils.py:520-530): W holds the M rows
+ * [lat_begin, lat_begin + M) of the full table; entries whose index falls outside are SKIPPED (their a' is
+ * reported as 0), so each shard's output is a partial sum to be combined by a reduce-scatter. lat_begin = 0
+ * and M = full table size is the unsharded case. post_enc / post_scale are indexed by the LOCAL row. */
 #define CLT_DECODE_ACCUMULATE 1 /* out += ... instead of out = ...                                   */
 #define CLT_DECODE_ROUND_ACTS 2 /* round a' to bf16 first: top_acts.to(self.dtype), sparse_coder.py:660 */
 int clt_decode_fwd(const int64_t* idx, const void* v, int v_dtype, const float* post_enc, const float* post_scale,
-                   const void* W, int w_dtype, int64_t M, int d, const float* bias, void* out, int out_dtype,
-                   int flags, float* acts_out, int64_t N, int k, clt_stream_t stream);
+                   const void* W, int w_dtype, int64_t M, int64_t lat_begin, int d, const float* bias, void* out,
+                   int out_dtype, int flags, float* acts_out, int64_t N, int k, clt_stream_t stream);
 
 /* Gradient w.r.t. the bag weights (xformers.py:167-171: g_acts[n,j] = G[n,:].W[idx[n,j],:])
  * with the backward of the post-encoder affine fused (autograd of sparse_coder.py:136-140):
@@ -96,20 +100,23 @@ int clt_decode_fwd(const int64_t* idx, const void* v, int v_dtype, const float* 
  *   grad_acts[n,j]  (+)= u                       (accumulate_grad_acts: CLT leaf grad, sparse_coder.py:72-76)
  *   e_post[n,j]  = u * (v>0)                     (NULL if post_enc grads are not needed)
  *   e_scale[n,j] = ga * (v + post_enc[idx]*(v>0))  (NULL unless post_scale is given)
- * G [N,d] in `g_dtype`; grad_acts/e_post/e_scale fp32 [N,k].                               */
+ * G [N,d] in `g_dtype`; grad_acts/e_post/e_scale fp32 [N,k].  Entries outside the shard
+ * [lat_begin, lat_begin + M) get 0 (and leave grad_acts untouched when accumulating).      */
 int clt_decode_bwd_acts(const int64_t* idx, const void* v, int v_dtype, const float* post_enc,
-                        const float* post_scale, const void* W, int w_dtype, int64_t M, int d, const void* G,
-                        int g_dtype, float* grad_acts, int accumulate_grad_acts, float* e_post, float* e_scale,
-                        int64_t N, int k, clt_stream_t stream);
+                        const float* post_scale, const void* W, int w_dtype, int64_t M, int64_t lat_begin, int d,
+                        const void* G, int g_dtype, float* grad_acts, int accumulate_grad_acts, float* e_post,
+                        float* e_scale, int64_t N, int k, clt_stream_t stream);
 
 /* ------------------------------------------------------------------ segments
  * Stable sort of the N*k (token, slot) entries by latent: replaces the COO sort of
  * kernels.py:42-51 and the count/cumsum/reverse-map kernels of xformers.py:93-122,
  * deterministically (entries of one latent stay in ascending entry id).
- *   perm [N*k] int32: entry ids (n*k + j) grouped by latent; offsets [M+1] int32.  */
+ *   perm [N*k] int32: entry ids (n*k + j) grouped by latent; offsets [M+1] int32.
+ * Sharded: only entries with idx in [lat_begin, lat_begin + M) form segments (local row = idx - lat_begin);
+ * the others are sorted behind offsets[M].                                            */
 size_t clt_segments_workspace_bytes(int64_t n_entries, int64_t M);
-int clt_segments_build(const int64_t* idx, int64_t n_entries, int64_t M, int32_t* perm, int32_t* offsets,
-                       void* workspace, size_t workspace_bytes, clt_stream_t stream);
+int clt_segments_build(const int64_t* idx, int64_t n_entries, int64_t M, int64_t lat_begin, int32_t* perm,
+                       int32_t* offsets, void* workspace, size_t workspace_bytes, clt_stream_t stream);
 
 /* sparse^T @ dense over prebuilt segments: replaces triton_sparse_transpose_dense_matmul
  * (kernels.py:14-54,113-216: encoder grad-W, fused_encoder.py:150-155) and
@@ -141,6 +148,18 @@ size_t clt_fvu_workspace_bytes(int64_t N, int d);
 int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask, int64_t N,
                     int d, float gscale, float* out_scalars, void* G, int g_dtype, void* workspace,
                     size_t workspace_bytes, clt_stream_t stream);
+
+/* The three stages of the FVU as separate entry points, for TOKEN-SHARDED targets (tensor parallel: each GPU
+ * holds its own tokens of y / yhat after the reduce-scatter).  The caller all-reduces (SUM) colsum_count[d+1]
+ * after stage 1 and l2tv[2] after stage 2 -- the scalar / [d] all-reduces DTensor generates for
+ * sparse_coder.py:214-221.  colsum_count = (sum_n m*y per column, then sum_n m); l2tv = (l2, tv).   */
+int clt_fvu_colsum(const void* y, int y_dtype, const uint8_t* mask, int64_t N, int d, float* colsum_count,
+                   void* workspace, size_t workspace_bytes, clt_stream_t stream);
+int clt_fvu_partial(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask, int64_t N,
+                    int d, const float* colsum_count, float* l2tv, void* workspace, size_t workspace_bytes,
+                    clt_stream_t stream);
+int clt_fvu_grad(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask, int64_t N, int d,
+                 const float* l2tv, float gscale, float* out_scalars, void* G, int g_dtype, clt_stream_t stream);
 
 /* ------------------------------------------------------------------ Adam
  * torch.optim.Adam defaults (trainer.py:178-186: betas=(b1,b2), eps 1e-8, no weight decay,

@@ -1,0 +1,145 @@
+"""GPU tests of the latent-shard kernel paths and of the explicit engine (tp = 1) against the oracle."""
+import math
+
+import pytest
+import torch
+
+from oracle import clt_oracle as O
+from oracle import ops_cpu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from clt_training_amd import hip_ops
+    return hip_ops
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_sharded_decode_sums_to_full(ops, dtype, tp):
+    """Partial decodes over latent shards (compacted, not masked) add up to the unsharded decode; every
+    (token, slot) gradient entry is produced by exactly one shard."""
+    g = torch.Generator().manual_seed(tp)
+    N, d, M, k = 130, 256, 1024, 70
+    W = (torch.randn(M, d, generator=g) / math.sqrt(d)).to(dtype)
+    v = torch.rand(N, k, generator=g)
+    v[:, ::6] = 0
+    idx = torch.stack([torch.randperm(M, generator=g)[:k] for _ in range(N)])
+    pe, ps = 0.1 * torch.randn(M, generator=g), 1 + 0.1 * torch.randn(M, generator=g)
+    G = torch.randn(N, d, generator=g).to(dtype)
+    full, acts_full = ops.decode_fwd(idx.to(DEV), v.to(DEV), W.to(DEV), post_enc=pe.to(DEV), post_scale=ps.to(DEV), want_acts=True,
+                                     out_dtype=torch.float32)
+    ga_full, ep_full, es_full = ops.decode_bwd_acts(idx.to(DEV), v.to(DEV), W.to(DEV), G.to(DEV), post_enc=pe.to(DEV),
+                                                    post_scale=ps.to(DEV), want_e_post=True)
+    Ml = M // tp
+    acc = torch.zeros(N, d, device=DEV)
+    acts = torch.zeros(N, k, device=DEV)
+    ga = torch.zeros(N, k, device=DEV)
+    ep = torch.zeros(N, k, device=DEV)
+    owners = torch.zeros(N, k, device=DEV)
+    for r in range(tp):
+        lo = r * Ml
+        Wl, pel, psl = W[lo:lo + Ml].to(DEV), pe[lo:lo + Ml].to(DEV), ps[lo:lo + Ml].to(DEV)
+        _, a = ops.decode_fwd(idx.to(DEV), v.to(DEV), Wl, post_enc=pel, post_scale=psl, want_acts=True, lat_begin=lo,
+                              out=acc, accumulate=True)
+        acts += a
+        owners += (a != 0)
+        _, e_post, e_scale = ops.decode_bwd_acts(idx.to(DEV), v.to(DEV), Wl, G.to(DEV), post_enc=pel, post_scale=psl,
+                                                 grad_acts=ga, want_e_post=True, lat_begin=lo)
+        ep += e_post
+        seg = ops.segments_build(idx.to(DEV), Ml, lat_begin=lo)
+        ref = ops_cpu.segments_build(idx, Ml, lat_begin=lo)
+        n_real = int(ref.offsets[-1])
+        assert torch.equal(seg.offsets.cpu().long(), ref.offsets)
+        assert torch.equal(seg.perm.cpu().long()[:n_real], ref.perm[:n_real])
+        gW = ops.spt_dense(seg, a.view(-1), G.to(DEV), out_dtype=torch.float32)
+        gW_ref = ops_cpu.spt_dense(ref, a.cpu().view(-1), G.float(), out_dtype=torch.float32)
+        torch.testing.assert_close(gW.cpu(), gW_ref, rtol=1e-4, atol=1e-4)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(acc, full, **tol)
+    torch.testing.assert_close(acts, acts_full, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ga, ga_full, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ep, ep_full, rtol=1e-4, atol=1e-4)
+    assert int(owners.max()) <= 1
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_fvu_stages_equal_fused(ops, masked):
+    g = torch.Generator().manual_seed(3)
+    N, d = 500, 128
+    y = torch.randn(N, d, generator=g).to(DEV)
+    yh = (y.cpu() + 0.3 * torch.randn(N, d, generator=g)).to(DEV)
+    m = None
+    if masked:
+        m = torch.ones(N, dtype=torch.bool)
+        m[::9] = False
+        m = m.to(DEV)
+    sc, G = ops.fvu_fwd_bwd(y, yh, m, gscale=0.5)
+    # two token shards
+    halves = [(y[:200], yh[:200], None if m is None else m[:200]), (y[200:], yh[200:], None if m is None else m[200:])]
+    cs = sum(ops.fvu_colsum(a, mm) for a, _, mm in halves)
+    l2tv = sum(ops.fvu_partial(a, b, mm, cs) for a, b, mm in halves)
+    outs = [ops.fvu_grad(a, b, mm, l2tv, gscale=0.5) for a, b, mm in halves]
+    torch.testing.assert_close(outs[0][0], sc, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(torch.cat([outs[0][1], outs[1][1]]), G, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["clt", "sae"])
+def test_engine_tp1_vs_oracle(case):
+    """The explicit engine on the HIP kernels (tp = 1), 3 train steps incl. step-0 init, Adam and schedule."""
+    import sys
+    sys.path.insert(0, "tests")
+    from test_tp_gloo import CASES, _make_problem, _oracle_layers
+    from clt_training_amd import SparseCoderConfig, TrainConfig
+    from clt_training_amd.engine import ShardedCoder
+    from clt_training_amd.tp import TPTrainer
+
+    sae_kw, L, cross = CASES["clt_skip_scale_norm_div" if case == "clt" else "sae"]
+    d, N = 16, 24
+    saes, steps = _make_problem(sae_kw, L, cross, d, N)
+    hooks = [f"h.{i}" for i in range(L)]
+    cfg = TrainConfig(sae=SparseCoderConfig(**sae_kw), hookpoints=hooks, cross_layer=cross, optimizer="adam", lr=1e-2,
+                      lr_warmup_steps=2)
+    coders = [ShardedCoder.from_full(s, 0, 1, DEV) for s in saes]
+    tr = TPTrainer(cfg, [None] * 4, device=DEV, input_widths={h: d for h in hooks}, coders=coders)
+    layers = _oracle_layers(saes)
+    state = [dict() for _ in range(L)]
+    for s, (xs, ys, m) in enumerate(steps):
+        if not sae_kw["transcode"]:
+            xs = ys
+        if s == 0:
+            for l in range(L):
+                O.step0_init(layers[l], xs[l], ys[l], sae_kw.get("normalize_io", False))
+        batch = {h: (xs[l].to(DEV), ys[l].to(DEV)) for l, h in enumerate(hooks)}
+        batch["loss_mask"] = m.to(DEV)
+        got = tr.step(batch)
+        r = O.clt_train_step(layers, xs, ys, m, sae_kw["k"], normalize_io=sae_kw.get("normalize_io", False),
+                             divide_cross_layer=sae_kw.get("divide_cross_layer", False))
+        torch.testing.assert_close(torch.tensor([float(got[h]) for h in hooks]), torch.stack(r.fvus), rtol=2e-4, atol=1e-6)
+        lr = 1e-2 * O.warmup_linear_factor(s, 2, 4)
+        for l, lp in enumerate(layers):
+            tensors = {"W_enc": lp.W_enc, "b_enc": lp.b_enc}
+            for i in range(len(lp.W_decs)):
+                tensors[f"W_decs.{i}"] = lp.W_decs[i]
+                tensors[f"b_decs.{i}"] = lp.b_decs[i]
+                if lp.W_skips[i] is not None:
+                    tensors[f"W_skips.{i}"] = lp.W_skips[i]
+                tensors[f"post_encs.{i}"] = lp.post_encs[i]
+                if lp.post_enc_scales is not None:
+                    tensors[f"post_enc_scales.{i}"] = lp.post_enc_scales[i]
+            for n, p in tensors.items():
+                mm, vv = state[l].get(n, (torch.zeros_like(p).double(), torch.zeros_like(p).double()))
+                pn, mm, vv = O.adam_step(p, r.grads[l][n], mm, vv, s + 1, lr)
+                p.copy_(pn.float())
+                state[l][n] = (mm, vv)
+    for l, lp in enumerate(layers):
+        c = coders[l]
+        torch.testing.assert_close(c.W_enc.detach().cpu(), lp.W_enc, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(c.b_enc.detach().cpu(), lp.b_enc, rtol=1e-4, atol=1e-5)
+        for i in range(len(lp.W_decs)):
+            torch.testing.assert_close(c.W_decs[i].detach().cpu(), lp.W_decs[i], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(c.b_decs[i].detach().cpu(), lp.b_decs[i], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(c.post_encs[i].detach().cpu(), lp.post_encs[i], rtol=1e-4, atol=1e-5)
