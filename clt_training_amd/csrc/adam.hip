@@ -11,6 +11,7 @@ __device__ __forceinline__ void adam_chunk(PT* __restrict__ p, const GT* __restr
                                            float inv_sqrt_bc2, float eps) {
   constexpr int V = 8;  // elements per thread per pass
   const int64_t nvec = n / V;
+#pragma unroll 4
   for (int64_t i = threadIdx.x; i < nvec; i += 256) {
     float pf[V], gf[V], mf[V], vf[V];
     if constexpr (sizeof(PT) == 2) {

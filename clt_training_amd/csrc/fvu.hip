@@ -17,8 +17,8 @@ struct FvuWs {
 };
 
 static int fvu_blocks(int64_t N) {
-  int64_t nb = (N + 15) / 16;
-  if (nb > 1024) nb = 1024;
+  int64_t nb = (N + 63) / 64;
+  if (nb > 128) nb = 128;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -29,16 +29,24 @@ __global__ __launch_bounds__(256) void fvu_colsum_kernel(const void* __restrict_
                                                          const uint8_t* __restrict__ mask, int64_t N, int d,
                                                          int64_t rpb, float* __restrict__ pcol,
                                                          float* __restrict__ pcnt) {
+  // grid = (row blocks, column blocks): one column per thread, rows of a block read coalesced across threads
   const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(N, r0 + rpb);
-  for (int c = threadIdx.x; c < d; c += 256) {
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
-      s += m * ld(y, y_dtype, r * d + c);
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c < d) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+      const float m0 = mask ? (mask[r] ? 1.f : 0.f) : 1.f, m1 = mask ? (mask[r + 1] ? 1.f : 0.f) : 1.f;
+      const float m2 = mask ? (mask[r + 2] ? 1.f : 0.f) : 1.f, m3 = mask ? (mask[r + 3] ? 1.f : 0.f) : 1.f;
+      s0 += m0 * ld(y, y_dtype, r * d + c);
+      s1 += m1 * ld(y, y_dtype, (r + 1) * d + c);
+      s2 += m2 * ld(y, y_dtype, (r + 2) * d + c);
+      s3 += m3 * ld(y, y_dtype, (r + 3) * d + c);
     }
-    pcol[(int64_t)blockIdx.x * d + c] = s;
+    for (; r < r1; ++r) s0 += (mask ? (mask[r] ? 1.f : 0.f) : 1.f) * ld(y, y_dtype, r * d + c);
+    pcol[(int64_t)blockIdx.x * d + c] = (s0 + s1) + (s2 + s3);
   }
-  if (threadIdx.x == 0) {
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
     float cnt = 0.f;
     for (int64_t r = r0; r < r1; ++r) cnt += mask ? (mask[r] ? 1.f : 0.f) : 1.f;
     pcnt[blockIdx.x] = cnt;
@@ -175,7 +183,7 @@ extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int
   float* pcnt = pcol + (size_t)NB * d;
   float* mean = pcnt + NB;
   float* psc = mean + d + 1;
-  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
+  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB, (d + 255) / 256), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
   hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
                      d, mean);
   hipLaunchKernelGGL(fvu_partial_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d, rpb,
@@ -207,7 +215,7 @@ extern "C" int clt_fvu_colsum(const void* y, int y_dtype, const uint8_t* mask, i
   const int64_t rpb = (N + NB - 1) / NB;
   float* pcol = reinterpret_cast<float*>(workspace);
   float* pcnt = pcol + (size_t)NB * d;
-  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
+  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB, (d + 255) / 256), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
   hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
                      d, colsum_count);
   CLT_CHECK_LAUNCH("clt_fvu_colsum");

@@ -39,6 +39,30 @@ __global__ void seg_offsets_kernel(const int32_t* __restrict__ sorted_keys, int3
   for (int64_t r = lo; r <= hi; ++r) offsets[r] = (int32_t)i;
 }
 
+template <typename OT, int E>
+__device__ __forceinline__ void store_row_chunk(OT* p, const float (&a)[E]) {
+  if constexpr (sizeof(OT) == 2 && E == 8) {
+    Chunk<bf16_t>::store(p, a);
+  } else if constexpr (sizeof(OT) == 4 && E == 4) {
+    Chunk<float>::store(p, a);
+  } else if constexpr (sizeof(OT) == 4 && E == 8) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(a[0], a[1], a[2], a[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(a[4], a[5], a[6], a[7]);
+  } else {
+    uint2 u2;
+    u2.x = pack_bf16x2(a[0], a[1]);
+    u2.y = pack_bf16x2(a[2], a[3]);
+    *reinterpret_cast<uint2*>(p) = u2;
+  }
+}
+
+// One wave owns RW consecutive output rows.  Their segment bounds (one load) and all their entries (one
+// 64-lane load per 64 entries: entry id, weight, source row, owning output row) are fetched up front, so the
+// dependent chain offsets -> perm -> dense row is paid once per RW rows instead of once per row; the gathers of
+// consecutive output rows then issue back to back (most rows hold 0-8 entries).  Rows are finished in order:
+// when the owning row of the next entry changes, the accumulator is stored (zeros for empty rows) and cleared.
+constexpr int RW = 8;
+
 template <typename DT, typename OT, int CH, int U>
 __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ offsets, int64_t M,
@@ -48,37 +72,59 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
                                                         OT* __restrict__ out, float* __restrict__ rowsum) {
   constexpr int E = Chunk<DT>::E;
   const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= M) return;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (r0 >= M) return;
+  const int nrows = (int)min((int64_t)RW, M - r0);
   const int nchunks = d / E;
-  const int beg = offsets[r], end = offsets[r + 1];
+  const int my_off = lane <= nrows ? offsets[r0 + lane] : 0;  // lanes 0..nrows hold the RW+1 bounds
+  const int beg = readlane_i(my_off, 0), end = readlane_i(my_off, nrows);
+
   float acc[CH][E];
 #pragma unroll
   for (int c = 0; c < CH; ++c)
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
-  float rs = 0.f;
+  float rs = 0.f;   // wave-uniform row sum
+  int cur = 0;      // row (relative to r0) being accumulated
+
+  auto flush_until = [&](int upto) {  // store rows cur .. upto-1 (wave-uniform loop)
+    while (cur < upto) {
+      OT* orow = out + (r0 + cur) * (int64_t)d;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks) {
+          store_row_chunk<OT, E>(orow + ch * E, acc[c]);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+        }
+      }
+      if (rowsum && lane == 0) rowsum[r0 + cur] = rs;
+      rs = 0.f;
+      ++cur;
+    }
+  };
 
   for (int s0 = beg; s0 < end; s0 += 64) {
-    int my_n = 0;
+    int my_n = 0, my_row = 0;
     float my_w = 0.f;
-    if (s0 + lane < end) {
-      const int e = perm[s0 + lane];
+    const int pos = s0 + lane;
+    if (pos < end) {
+      const int e = perm[pos];
       float w = vals[e];
       if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
       my_w = w;
       my_n = e / k;
+#pragma unroll
+      for (int q = 1; q < RW; ++q) my_row += (q < nrows && pos >= readlane_i(my_off, q)) ? 1 : 0;
     }
-    rs += my_w;
     const int cnt = min(64, end - s0);
     for (int jj = 0; jj < cnt; jj += U) {
       uint4 raw[U][CH];
-      float w_u[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int jl = min(jj + u, cnt - 1);
         const int n = readlane_i(my_n, jl);
-        w_u[u] = (jj + u < cnt) ? readlane_f(my_w, jl) : 0.f;
         const char* row = reinterpret_cast<const char*>(dense) + (size_t)n * (size_t)d * sizeof(DT);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -88,44 +134,26 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        if (jj + u < cnt) {  // wave-uniform
+          const int row_e = readlane_i(my_row, jj + u);
+          const float w = readlane_f(my_w, jj + u);
+          if (row_e != cur) flush_until(row_e);
+          rs += w;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int ch = lane + 64 * c;
-          if (ch < nchunks) {
-            float x[E];
-            Chunk<DT>::expand(raw[u][c], x);
+          for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+              float x[E];
+              Chunk<DT>::expand(raw[u][c], x);
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[c][e] = fmaf(w_u[u], x[e], acc[c][e]);
+              for (int e = 0; e < E; ++e) acc[c][e] = fmaf(w, x[e], acc[c][e]);
+            }
           }
         }
       }
     }
   }
-
-  OT* orow = out + r * (int64_t)d;
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int ch = lane + 64 * c;
-    if (ch < nchunks) {
-      if constexpr (sizeof(OT) == 2 && E == 8) {
-        Chunk<bf16_t>::store(orow + ch * 8, acc[c]);
-      } else if constexpr (sizeof(OT) == 4 && E == 4) {
-        Chunk<float>::store(orow + ch * 4, acc[c]);
-      } else if constexpr (sizeof(OT) == 4 && E == 8) {
-        reinterpret_cast<float4*>(orow + ch * 8)[0] = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
-        reinterpret_cast<float4*>(orow + ch * 8)[1] = make_float4(acc[c][4], acc[c][5], acc[c][6], acc[c][7]);
-      } else {
-        uint2 u2;
-        u2.x = pack_bf16x2(acc[c][0], acc[c][1]);
-        u2.y = pack_bf16x2(acc[c][2], acc[c][3]);
-        *reinterpret_cast<uint2*>(orow + ch * 4) = u2;
-      }
-    }
-  }
-  if (rowsum) {
-    rs = wave_sum(rs);
-    if (lane == 0) rowsum[r] = rs;
-  }
+  flush_until(nrows);
 }
 
 __global__ void segment_sum_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets, int64_t M,
@@ -233,7 +261,7 @@ extern "C" int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_
   int chunks = d / E, ch = (chunks + 63) / 64;
   ch = ch <= 1 ? 1 : ch <= 2 ? 2 : ch <= 4 ? 4 : ch <= 8 ? 8 : ch <= 16 ? 16 : -1;
   CLT_UNSUPPORTED(ch > 0, "clt_spt_dense: d=%d too wide", d);
-  dim3 grid((unsigned)((M + 3) / 4));
+  dim3 grid((unsigned)((M + 4 * RW - 1) / (4 * RW)));
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (dense_dtype == CLT_BF16 && out_dtype == CLT_BF16)
