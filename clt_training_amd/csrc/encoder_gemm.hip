@@ -25,7 +25,7 @@
 // MFMA-bound: 2 * N * M * d flops per launch.
 #include <stdlib.h>
 
-#include "common.h"
+#include "gemm_fast.h"
 
 namespace clt {
 
@@ -34,33 +34,17 @@ __device__ uint4 g_zero_chunk[1];  // 16 zero bytes, source for padding lanes
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int TM = 256;    // latents per tile
-constexpr int TN = 256;    // tokens per tile
+constexpr int TM = GEMM_TM;  // latents per tile
+constexpr int TN = GEMM_TN;  // tokens per tile
 constexpr int ROWB = 64;   // bytes of K per row per step
 constexpr int OP_BYTES = TM * ROWB;  // 16 KiB per operand per stage
 constexpr int NSTAGE = 4;            // LDS ring: 3 k-steps of LDS-DMA in flight behind the one being multiplied
 constexpr int BIAS_OFF = 2 * OP_BYTES;      // each stage also carries the tile's 256 bias values (<= 1 KiB)
 constexpr int STAGE_BYTES = 2 * OP_BYTES + 1024;
-constexpr int PANEL = 8;             // token tiles per L2 panel
 constexpr int NTHREADS = 512;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-struct TileCoord {
-  int64_t lat0, tok0;
-};
-
-__device__ __forceinline__ TileCoord tile_of(int64_t id, int64_t nlt, int64_t ntt) {
-  const int64_t full = nlt * PANEL;
-  const int64_t p = id / full;
-  const int64_t rem = id - p * full;
-  const int64_t pt = min((int64_t)PANEL, ntt - p * PANEL);
-  TileCoord c;
-  c.lat0 = (rem / pt) * TM;
-  c.tok0 = (p * PANEL + rem % pt) * TN;
-  return c;
-}
 
 // One LDS-DMA of 16 B per lane: LDS[dst + 16 * lane] = *src.  Issued from inline asm so that hipcc
 // neither counts it nor drains it: with the builtin, hipcc puts s_waitcnt vmcnt(0) in front of the
@@ -358,6 +342,8 @@ extern "C" int clt_encoder_gemm_relu(const void* x, const void* W, int in_dtype,
   hipStream_t st = (hipStream_t)stream;
   const char* dbg_env = getenv("CLT_GEMM_DEBUG");  // timing experiments only (skip stores / MFMA / loads)
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  if (gemm_fast_supported(in_dtype, N, M, d) && !(dbg & 16))  // 16: force the generic kernel
+    return launch_gemm_fast(x, W, bias, bias_dtype, pre, out_dtype, N, M, d, (int)grid_n, dbg, st);
   if (in_dtype == CLT_BF16 && out_dtype == CLT_BF16)
     hipLaunchKernelGGL((encoder_gemm_kernel<bf16_t, bf16_t>), grid, dim3(NTHREADS), 0, st, (const bf16_t*)x,
                        (const bf16_t*)W, bias, bias_dtype, (bf16_t*)pre, N, M, d, nlt, ntt, dbg);
