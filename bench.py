@@ -47,7 +47,7 @@ def synth_batches(hooks, N, d, n_batches, dtype, device, seed=0):
 
 def algorithmic_work(name, N, d, M, k, es, P_total):
     """Algorithmic flops / bytes per launch -> (amount, 'flop'|'byte')."""
-    if name == "clt_encoder_gemm_relu":
+    if name in ("clt_encoder_gemm_relu", "clt_encode_topk_fwd"):  # the fused call is priced as its GEMM alone
         return 2.0 * N * d * M, "flop"
     if name == "clt_topk_rows":
         return N * M * es, "byte"

@@ -342,8 +342,23 @@ extern "C" int clt_encoder_gemm_relu(const void* x, const void* W, int in_dtype,
   hipStream_t st = (hipStream_t)stream;
   const char* dbg_env = getenv("CLT_GEMM_DEBUG");  // timing experiments only (skip stores / MFMA / loads)
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  if (gemm_fast_supported(in_dtype, N, M, d) && !(dbg & 16))  // 16: force the generic kernel
-    return launch_gemm_fast(x, W, bias, bias_dtype, pre, out_dtype, N, M, d, (int)grid_n, dbg, st);
+  if (gemm_fast_supported(in_dtype, N, M, d) && !(dbg & 16)) {  // 16: force the generic kernel
+    FastArgs a = {};
+    a.x = (const char*)x;
+    a.W = (const char*)W;
+    a.bias = (const char*)bias;
+    a.bias_esize = bias_dtype == CLT_BF16 ? 2 : 4;
+    a.pre = pre;
+    a.ldp = M;
+    a.N = N;
+    a.M = M;
+    a.kbytes = d * 2;
+    a.nlt = (int)nlt;
+    a.ntt = (int)ntt;
+    a.lt_mode = LT_ALL;
+    a.dbg = dbg;
+    return launch_gemm_fast(a, out_dtype, false, num_cus(), st);
+  }
   if (in_dtype == CLT_BF16 && out_dtype == CLT_BF16)
     hipLaunchKernelGGL((encoder_gemm_kernel<bf16_t, bf16_t>), grid, dim3(NTHREADS), 0, st, (const bf16_t*)x,
                        (const bf16_t*)W, bias, bias_dtype, (bf16_t*)pre, N, M, d, nlt, ntt, dbg);
@@ -360,19 +375,35 @@ extern "C" int clt_encoder_gemm_relu(const void* x, const void* W, int in_dtype,
   return CLT_OK;
 }
 
+// Workspace: the pre-activation matrix of the plain path (which is also the fused path's fallback), with the
+// fused path's smaller buffers laid over its front, and a 4 KiB tail that holds the fallback flag.
 extern "C" size_t clt_encode_topk_workspace_bytes(int64_t N, int64_t M, int out_dtype) {
-  if (N <= 0 || M <= 0) return 256;
-  return align_up((size_t)N * (size_t)M * dtype_size(out_dtype), 256);
+  if (N <= 0 || M <= 0) return 4096 + 256;
+  return align_up((size_t)N * (size_t)M * dtype_size(out_dtype), 256) + 4096;
 }
 
 extern "C" int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, const void* bias, int bias_dtype,
                                    int64_t N, int64_t M, int d, int k, void* out_vals, int out_dtype,
                                    int64_t* out_idx, void* workspace, size_t workspace_bytes, clt_stream_t stream) {
   CLT_CHECK_ARG(workspace, "clt_encode_topk_fwd: null workspace");
-  if (workspace_bytes < clt_encode_topk_workspace_bytes(N, M, out_dtype)) {
-    set_error("clt_encode_topk_fwd: workspace too small (%zu < %zu)", workspace_bytes,
-              clt_encode_topk_workspace_bytes(N, M, out_dtype));
+  CLT_CHECK_ARG(x && W && out_vals && out_idx, "clt_encode_topk_fwd: null pointer");
+  CLT_CHECK_ARG(aligned16(workspace), "clt_encode_topk_fwd: workspace must be 16-byte aligned");
+  const size_t need = clt_encode_topk_workspace_bytes(N, M, out_dtype);
+  if (workspace_bytes < need) {
+    set_error("clt_encode_topk_fwd: workspace too small (%zu < %zu)", workspace_bytes, need);
     return CLT_ERR_WORKSPACE;
+  }
+  if (N == 0) return CLT_OK;
+  const char* dbg_env = getenv("CLT_GEMM_DEBUG");  // 32: never take the fused path
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  if (!(dbg & (16 | 32)) && valid_dtype(in_dtype) && valid_dtype(out_dtype) && aligned16(x) && aligned16(W) &&
+      (!bias || (valid_dtype(bias_dtype) && aligned16(bias))) && k >= 1 && k <= M) {
+    const FusedPlan pl = fused_plan(in_dtype, out_dtype, N, M, d, k);
+    if (pl.ok && pl.bytes <= need - 4096) {
+      char* ws = (char*)workspace;
+      return launch_fused_encode_topk(pl, x, W, bias, bias_dtype, N, M, d, k, out_vals, out_idx, ws,
+                                      (int*)(ws + need - 4096), num_cus(), dbg, (hipStream_t)stream);
+    }
   }
   int rc = clt_encoder_gemm_relu(x, W, in_dtype, bias, bias_dtype, workspace, out_dtype, N, M, d, stream);
   if (rc != CLT_OK) return rc;

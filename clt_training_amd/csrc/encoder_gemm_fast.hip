@@ -19,6 +19,7 @@
 //   read; the same barrier frees the slot of stage s-1 for the LDS-DMAs of stage s+3.
 // MFMA-bound: 2 * N * M * d flops per launch.
 #include "gemm_fast.h"
+#include "topk_select.h"
 
 namespace clt {
 namespace {
@@ -32,10 +33,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int ROWB = 64;                    // bytes of K per row per k-step (32 bf16)
 constexpr int OP_BYTES = GEMM_TM * ROWB;    // 16 KiB per operand per stage
 constexpr int NSTAGE = 4;
-constexpr int BIAS_OFF = 2 * OP_BYTES;
-constexpr int STAGE_BYTES = 2 * OP_BYTES + 1024;
+constexpr int AUX_OFF = 2 * OP_BYTES;     // per stage and wave 1 KiB: [0, 256) bias of 64 latents, [512, 1024) tau of 128 tokens
+constexpr int STAGE_BYTES = 2 * OP_BYTES + 4096;
 constexpr int NTHREADS = 256;
-constexpr int NDMA = 9;                     // LDS-DMAs per wave per stage: 4 W pieces, 4 x pieces, 1 bias piece
+constexpr int NDMA = 9;                     // LDS-DMAs per wave per stage: 4 W pieces, 4 x pieces, 1 bias/tau piece
 constexpr int NSTORE = 64;                  // store instructions per wave in the epilogue of an interior tile
 
 #define CLT_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -82,12 +83,24 @@ __device__ __forceinline__ float acc_read(float a) {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <typename OT>
-__global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __restrict__ xb, const char* __restrict__ Wb,
-                                                                 const char* __restrict__ bias, int bias_esize,
-                                                                 OT* __restrict__ pre, int64_t N, int64_t M, int kbytes,
-                                                                 int nlt, int ntt, int dbg) {
+// Latent tiles can be a strided subset of W's 256-row tiles, so that one kernel serves the three launches of
+// the fused encode+top-k (gemm_fast.h): virtual tile v -> actual tile.
+__host__ __device__ __forceinline__ int lt_actual(int v, int mode, int S) {
+  if (mode == LT_SAMPLE) return v * S;                 // every S-th tile
+  if (mode == LT_REST) return v + v / (S - 1) + 1;     // all the others
+  return v;
+}
+
+// MODE 0: store relu(pre) (OT = bf16 or f32).  MODE 1: per-token threshold filter, no pre matrix (see FastArgs).
+template <typename OT, int MODE>
+__global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p) {
   __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE_BYTES];
+  if (p.gate && *p.gate == 0) return;  // fallback launch: runs only if the fused path raised its flag
+  const char* __restrict__ xb = p.x;
+  const char* __restrict__ Wb = p.W;
+  const char* __restrict__ bias = p.bias;
+  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt, ntt = p.ntt, dbg = p.dbg;
+  const int64_t N = p.N, M = p.M;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -109,13 +122,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
   const char* zero = reinterpret_cast<const char*>(g_zero16);
 
-  auto coords = [&](int id, int& lt, int& tt) {  // see tile_of (gemm_fast.h)
+  auto coords = [&](int id, int& lt, int& tt) {  // see tile_of (gemm_fast.h); lt is the VIRTUAL latent tile
     const int full = nlt * GEMM_PANEL;
-    const int p = id / full, rem = id - p * full;
-    const int left = ntt - p * GEMM_PANEL;
+    const int pp = id / full, rem = id - pp * full;
+    const int left = ntt - pp * GEMM_PANEL;
     const int pt = left < GEMM_PANEL ? left : GEMM_PANEL;
     lt = uni(rem / pt);
-    tt = uni(p * GEMM_PANEL + rem % pt);
+    tt = uni(pp * GEMM_PANEL + rem % pt);
   };
 
   // ---- loader state: runs three stages ahead of the multiplier, possibly in the next tile.  Past the last
@@ -124,15 +137,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
   int ld_t = 0, ld_ks = 0, ld_slot = 0;
   const char* ldW = Wb;
   const char* ldX = xb;
-  const char* ldB = zero;
+  const char* ldA = zero;  // per-lane source of the aux piece: bias chunk (lanes < nl) or tau chunk (lanes >= 32)
   uint32_t voffW[4], voffX[4];
   const int nl = 64 * bias_esize / 16;  // lanes of the bias piece (this wave's 64 latents)
+  const bool aux_lane = lane < nl || (MODE == 1 && lane >= 32);
   auto loader_tile = [&](int lt, int tt) {
-    const int64_t lat0 = (int64_t)lt * GEMM_TM, tok0 = (int64_t)tt * GEMM_TN;
+    const int64_t lat0 = (int64_t)lt_actual(lt, p.lt_mode, p.lt_S) * GEMM_TM, tok0 = (int64_t)tt * GEMM_TN;
     ldW = Wb + lat0 * kbytes;
     ldX = xb + tok0 * kbytes;
     // rows past the end re-read the last row (their products are never stored)
-    const int maxW = (int)(M - 1 - lat0 < GEMM_TM ? M - 1 - lat0 : GEMM_TM), maxX = (int)(N - 1 - tok0 < GEMM_TN ? N - 1 - tok0 : GEMM_TN);
+    const int maxW = (int)(M - 1 - lat0 < GEMM_TM ? M - 1 - lat0 : GEMM_TM);
+    const int maxX = (int)(N - 1 - tok0 < GEMM_TN ? N - 1 - tok0 : GEMM_TN);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = (wave + 4 * q) * 16 + (lane >> 2);
@@ -142,7 +157,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
     }
     const int epc = 16 / bias_esize;
     const int64_t lat = lat0 + 64 * wave + lane * epc;
-    ldB = (bias && lat + epc <= M) ? bias + lat * bias_esize : zero;
+    ldA = (bias && lat + epc <= M) ? bias + lat * bias_esize : zero;
+    if (MODE == 1 && lane >= 32)  // tau is padded to a multiple of 256 tokens
+      ldA = reinterpret_cast<const char*>(p.tau + tok0 + wn * 128 + (lane - 32) * 4);
   };
   auto dma = [&](int q, uint32_t stage_lds, int kb0) {
     if (q < 4) {
@@ -150,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
     } else if (q < 8) {
       dma_s(ldX + kb0, voffX[q - 4], stage_lds + OP_BYTES + (wave + 4 * (q - 4)) * 1024);
     } else {
-      if (lane < nl) dma_v(ldB, stage_lds + BIAS_OFF + wave * 64 * bias_esize);
+      if (aux_lane) dma_v(ldA, stage_lds + AUX_OFF + wave * 1024);
     }
   };
   auto loader_advance = [&]() {
@@ -170,11 +187,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
   const uint32_t fa = (uint32_t)((wm * 128 + r32) * ROWB);
   const uint32_t fb = (uint32_t)(OP_BYTES + (wn * 128 + r32) * ROWB);
   const uint32_t pk[2] = {(uint32_t)(((0 + h) ^ swz) * 16), (uint32_t)(((2 + h) ^ swz) * 16)};
-  // piece p of a (stage, kk) fragment set, in the order the MFMAs need them: A0 B0 B1 B2 B3 A1 A2 A3
-  auto read_piece = [&](const char* st, int kk, int p, uint4 (&A)[4], uint4 (&B)[4]) {
-    if (p == 0) A[0] = *reinterpret_cast<const uint4*>(st + fa + pk[kk]);
-    else if (p <= 4) B[p - 1] = *reinterpret_cast<const uint4*>(st + fb + (p - 1) * 32 * ROWB + pk[kk]);
-    else A[p - 4] = *reinterpret_cast<const uint4*>(st + fa + (p - 4) * 32 * ROWB + pk[kk]);
+  // piece pc of a (stage, kk) fragment set, in the order the MFMAs need them: A0 B0 B1 B2 B3 A1 A2 A3
+  auto read_piece = [&](const char* st, int kk, int pc, uint4 (&A)[4], uint4 (&B)[4]) {
+    if (pc == 0) A[0] = *reinterpret_cast<const uint4*>(st + fa + pk[kk]);
+    else if (pc <= 4) B[pc - 1] = *reinterpret_cast<const uint4*>(st + fb + (pc - 1) * 32 * ROWB + pk[kk]);
+    else A[pc - 4] = *reinterpret_cast<const uint4*>(st + fa + (pc - 4) * 32 * ROWB + pk[kk]);
   };
 
   f32x16 acc[4][4];
@@ -189,10 +206,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
     uint4 Ab[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int off = wm * 128 + i * 32 + r32;
+      const int off = wm * 128 + i * 32 + r32;  // latent in the tile: aux piece of wave off / 64
+      const char* bp = st + AUX_OFF + (off >> 6) * 1024 + (off & 63) * bias_esize;
       float b;
-      if (bias_esize == 4) b = *reinterpret_cast<const float*>(st + BIAS_OFF + off * 4);
-      else b = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(st + BIAS_OFF + off * 2));
+      if (bias_esize == 4) b = *reinterpret_cast<const float*>(bp);
+      else b = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(bp));
       const uint32_t u0 = __float_as_uint(b) & 0xffff0000u;  // truncation splits: every remainder is exact
       const float r1 = b - __uint_as_float(u0);
       const uint32_t u1 = __float_as_uint(r1) & 0xffff0000u;
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
   coords(xstart + bi, cur_lt, cur_tt);
   loader_tile(cur_lt, cur_tt);
 #pragma unroll 1
-  for (int p = 0; p < 3; ++p) {
+  for (int pp = 0; pp < 3; ++pp) {
     const uint32_t st = lds0 + (uint32_t)ld_slot * STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < NDMA; ++q) dma(q, st, ld_ks * ROWB);
@@ -223,81 +241,134 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-  for (int p = 0; p < 8; ++p) read_piece(lds, 0, p, A0, B0);
+  for (int pc = 0; pc < 8; ++pc) read_piece(lds, 0, pc, A0, B0);
   init_acc(lds);
 
   int ks = 0, t_idx = 0;
-  int stores_behind = 0;  // k-steps (2, 1) for which the NSTORE stores of the last epilogue are still among the
-                          // youngest operations of the vmcnt queue
+  // Stage s+1 has landed once only the operations issued after its LDS-DMAs are outstanding: the NDMA DMAs of
+  // stage s+2, plus -- for the two k-steps after an epilogue -- the epilogue's stores, which are younger than the
+  // DMAs of stage s+1.  vmcnt(n) is safe for any n <= that count (the counter saturates at 63): wait_allow.
+  int stores_behind = 0, wait_allow = NDMA;
 #pragma unroll 1
   for (int s = 0; s < total; ++s) {
     const char* cb = lds + (s & 3) * STAGE_BYTES;
     const char* nb = lds + ((s + 1) & 3) * STAGE_BYTES;
     const uint32_t ld_stage = lds0 + (uint32_t)ld_slot * STAGE_BYTES;
     const int kb0 = ld_ks * ROWB;
-    // Stage s+1 has landed once only the operations issued after its LDS-DMAs are outstanding: the NDMA DMAs of
-    // stage s+2, plus the epilogue's NSTORE stores while they are younger than the DMAs of stage s+1.
-    // vmcnt(n) is safe for any n <= that count (the counter saturates at 63).
-    const bool many = stores_behind > 0;
+    const int allow = stores_behind > 0 ? wait_allow : NDMA;
     const bool last_k = ks + 1 == nsteps;
 
-    {
-      CLT_FENCE();
+    CLT_FENCE();
 #pragma unroll
-      for (int t = 0; t < 32; ++t) {
-        const int kk = t >> 4, i = (t >> 2) & 3, j = t & 3;
-        if (kk == 0) acc[i][j] = mfma(A0[i], B0[j], acc[i][j]);
-        else acc[i][j] = mfma(A1[i], B1[j], acc[i][j]);
-        CLT_FENCE();
-        if (t == 1) {
-          if (many) asm volatile("s_waitcnt vmcnt(63)\n\ts_barrier" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
-        }
-        if (t < 8) read_piece(cb, 1, t, A1, B1);
-        if (t >= 16 && t < 24) read_piece(nb, 0, t - 16, A0, B0);
-        if (t % 3 == 2 && t <= 26) dma((t - 2) / 3, ld_stage, kb0);
-        CLT_FENCE();
+    for (int t = 0; t < 32; ++t) {
+      const int kk = t >> 4, i = (t >> 2) & 3, j = t & 3;
+      if (kk == 0) acc[i][j] = mfma(A0[i], B0[j], acc[i][j]);
+      else acc[i][j] = mfma(A1[i], B1[j], acc[i][j]);
+      CLT_FENCE();
+      if (t == 1) {
+        if (allow >= 63) asm volatile("s_waitcnt vmcnt(63)\n\ts_barrier" ::: "memory");
+        else if (allow >= 45) asm volatile("s_waitcnt vmcnt(45)\n\ts_barrier" ::: "memory");
+        else if (allow >= 27) asm volatile("s_waitcnt vmcnt(27)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
       }
+      if (t < 8) read_piece(cb, 1, t, A1, B1);
+      if (t >= 16 && t < 24) read_piece(nb, 0, t - 16, A0, B0);
+      if (t % 3 == 2 && t <= 26) dma((t - 2) / 3, ld_stage, kb0);
+      CLT_FENCE();
     }
     loader_advance();
     if (stores_behind > 0) --stores_behind;
 
-    // ---- epilogue at the end of a tile: ReLU, one rounding, 4 consecutive latents per store
     if (last_k) {
-      const int64_t lat0 = (int64_t)cur_lt * GEMM_TM, tok0 = (int64_t)cur_tt * GEMM_TN;
-      const bool interior = tok0 + GEMM_TN <= N && lat0 + GEMM_TM <= M && (M & 3) == 0;
-      if (!(dbg & 1)) {
-        // One code path for interior and edge tiles (two paths make hipcc hoist all 256 accumulator reads above
-        // the branch, which spills).  M is a multiple of 8, so a run of 4 latents starting at a multiple of 4 is
-        // inside or outside as a whole and the test does not depend on the lane half.
-        const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);  // wave-uniform
+      const int lt_act = lt_actual(cur_lt, p.lt_mode, p.lt_S);
+      const int64_t lat0 = (int64_t)lt_act * GEMM_TM, tok0 = (int64_t)cur_tt * GEMM_TN;
+      // M is a multiple of 8, so a run of 4 latents starting at a multiple of 4 is inside or outside M as a whole
+      // and the test does not depend on the lane half.
+      const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);  // wave-uniform
+      if constexpr (MODE == 0) {
+        // ---- store epilogue: ReLU, one rounding, 4 consecutive latents per store.  One code path for interior
+        //      and edge tiles (two paths make hipcc hoist all 256 accumulator reads above the branch: spills).
+        if (!(dbg & 1)) {
+          OT* pre = reinterpret_cast<OT*>(p.pre);
+          const bool interior = tok0 + GEMM_TN <= N && lat_left == 128;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t tok = tok0 + wn * 128 + j * 32 + r32;
+            const bool tok_ok = tok < N;
+            OT* prow = pre + tok * p.ldp + (int64_t)cur_lt * GEMM_TM + wm * 128 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                if (tok_ok && i * 32 + 8 * g < lat_left) {
+                  float v[4];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc_read(acc[i][j][4 * g + q]), 0.f);
+                  if constexpr (sizeof(OT) == 2) {
+                    uint2 u;
+                    u.x = pack_bf16x2(v[0], v[1]);
+                    u.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(prow + i * 32 + 8 * g) = u;
+                  } else {
+                    *reinterpret_cast<float4*>(prow + i * 32 + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                  }
+                }
+              }
+              CLT_FENCE();
+            }
+          }
+          if (interior) stores_behind = 2, wait_allow = NDMA + NSTORE;
+        }
+      } else {
+        // ---- filter epilogue: an accumulator that reaches its token's threshold (the lower edge of the bf16
+        //      rounding interval of the k-th best of the sample tiles, from pass A) is appended, as
+        //      (bf16 bits << 16 | position in the list's 64 latents), to the private list of this (token, latent
+        //      tile, latent half, lane half); the list's length goes to counts.  No atomics, no pre matrix.
+        const int list = (cur_lt * 2 + wm) * 2 + h;
+        float tl[4];
+        int cnt[4];
+        uint32_t* lp[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t tok = tok0 + wn * 128 + j * 32 + r32;
-          const bool tok_ok = tok < N;
-          OT* prow = pre + tok * M + lat0 + wm * 128 + 4 * h;
+          const float t = *reinterpret_cast<const float*>(cb + AUX_OFF + wave * 1024 + 512 + (j * 32 + r32) * 4);
+          tl[j] = tok < N ? t : __builtin_inff();
+          cnt[j] = 0;
+          lp[j] = p.lists + (tok * p.nL + list) * FUSED_SLOTS;
+        }
+        int nst = 0;  // store instructions issued (wave-uniform)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              if (tok_ok && i * 32 + 8 * g < lat_left) {
-                float v[4];
+          for (int g = 0; g < 4; ++g) {
+            if (i * 32 + 8 * g < lat_left) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc_read(acc[i][j][4 * g + q]), 0.f);
-                if constexpr (sizeof(OT) == 2) {
-                  uint2 u;
-                  u.x = pack_bf16x2(v[0], v[1]);
-                  u.y = pack_bf16x2(v[2], v[3]);
-                  *reinterpret_cast<uint2*>(prow + i * 32 + 8 * g) = u;
-                } else {
-                  *reinterpret_cast<float4*>(prow + i * 32 + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+              for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float a = acc_read(acc[i][j][4 * g + q]);
+                  const bool hit = a >= tl[j];
+                  if (__ballot(hit) != 0ull) {
+                    ++nst;
+                    if (hit) {
+                      if (cnt[j] < FUSED_SLOTS && !(dbg & 1))
+                        lp[j][cnt[j]] = (f32_to_bf16_bits(a) << 16) | (uint32_t)(i * 16 + g * 4 + q);
+                      ++cnt[j];
+                    }
+                  }
                 }
               }
             }
             CLT_FENCE();
           }
         }
-        if (interior) stores_behind = 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t tok = tok0 + wn * 128 + j * 32 + r32;
+          if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(cnt[j] < 255 ? cnt[j] : 255);
+        }
+        stores_behind = 2;
+        wait_allow = NDMA + (nst < 54 ? nst : 54);
       }
       ks = 0;
       if (++t_idx < my_tiles) {
@@ -311,6 +382,82 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const char* __re
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing fetches
 }
 
+// tau[tok] = the smallest f32 whose bf16 rounding can reach the k-th best sample value of the token (half a bf16
+// ulp below it: the rounding interval's lower edge; including the edge itself only adds candidates), or the
+// smallest positive f32 when the sample holds fewer than k positive values.  Padding tokens get +inf.
+__global__ void tau_kernel(const uint16_t* __restrict__ svals, int k, int64_t N, int64_t Npad, float* __restrict__ tau) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Npad) return;
+  float v = __builtin_inff();
+  if (t < N) {
+    const uint32_t bits = (uint32_t)svals[t * k + k - 1] << 16;
+    v = bits == 0u ? __uint_as_float(1u) : __uint_as_float(bits - 0x8000u);
+  }
+  tau[t] = v;
+}
+
+// Final selection of the fused path: one wave per token merges the sample's top-k (pass A) with the token's
+// candidate lists (pass B) under the same 64-bit key order as clt_topk_rows, and raises *flag when a list
+// overflowed (the caller's gated fallback launches then redo the token batch the plain way).
+template <int S, int R>
+__global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __restrict__ svals,
+                                                           const int64_t* __restrict__ sidx,
+                                                           const uint8_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ lists, int nL, int lt_S, int64_t N,
+                                                           int64_t M, int k, bf16_t* __restrict__ out_vals,
+                                                           int64_t* __restrict__ out_idx, int* __restrict__ flag) {
+  constexpr int C = (R - S) * 64;
+  __shared__ u64 lds_q[4][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
+  if (tok >= N) return;
+  WaveSelect<S, R> ws;
+  ws.init(lds_q[wave], lane, k);
+  // the sample's best k: column c of the sample matrix is latent (c / 256) * S * 256 + c % 256
+  for (int e0 = 0; e0 < k; e0 += 64) {
+    const int e = e0 + lane;
+    float v = -1.f;
+    unsigned col = 0;
+    if (e < k) {
+      v = bf16_bits_to_f32(svals[tok * k + e]);
+      const int64_t c = sidx[tok * k + e];
+      col = (unsigned)((c >> 8) * lt_S * 256 + (c & 255));
+    }
+    ws.offer(v > 0.f, v, col);
+  }
+  if (ws.cnt > 0) ws.flush();  // the threshold is now the sample's k-th value
+  bool over = false;
+  const uint8_t* crow = counts + tok * nL;
+  const uint32_t* lrow = lists + tok * (int64_t)nL * FUSED_SLOTS;
+  for (int l0 = 0; l0 < nL; l0 += 64) {
+    const int l = l0 + lane;
+    int c = l < nL ? (int)crow[l] : 0;
+    if (c > FUSED_SLOTS) over = true, c = FUSED_SLOTS;
+    // list l = ((virtual tile * 2 + wm) * 2 + h); position pos = i * 16 + g * 4 + q
+    const int vt = l >> 2, wm = (l >> 1) & 1, hh = l & 1;
+    const unsigned lat_base = (unsigned)lt_actual(vt, LT_REST, lt_S) * 256u + wm * 128 + 4 * hh;
+    int cmax = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+    for (int e = 0; e < cmax; ++e) {
+      float v = -1.f;
+      unsigned col = 0;
+      if (e < c) {
+        const uint32_t ent = lrow[(int64_t)l * FUSED_SLOTS + e];
+        v = __uint_as_float(ent & 0xffff0000u);
+        const unsigned pos = ent & 63u;
+        col = lat_base + (pos >> 4) * 32 + ((pos >> 2) & 3) * 8 + (pos & 3);
+      }
+      ws.offer(v >= ws.thr_val && v > 0.f, v, col);
+    }
+  }
+  if (ws.cnt > 0) ws.flush();
+  if (__ballot(over) != 0ull) {
+    if (lane == 0) atomicOr(flag, 1);
+  }
+  write_out<S, R>(ws, out_vals, CLT_BF16, tok, out_idx, k);
+}
+
 }  // namespace
 
 bool gemm_fast_supported(int in_dtype, int64_t N, int64_t M, int d) {
@@ -320,18 +467,122 @@ bool gemm_fast_supported(int in_dtype, int64_t N, int64_t M, int d) {
          kbytes * GEMM_TM < (1ll << 31) && nlt * ntt * (kbytes / ROWB) < (1ll << 30);
 }
 
-int launch_gemm_fast(const void* x, const void* W, const void* bias, int bias_dtype, void* pre, int out_dtype,
-                     int64_t N, int64_t M, int d, int grid, int dbg, hipStream_t st) {
-  const int64_t nlt = (M + GEMM_TM - 1) / GEMM_TM, ntt = (N + GEMM_TN - 1) / GEMM_TN;
-  const int esize = bias_dtype == CLT_BF16 ? 2 : 4;
-  if (out_dtype == CLT_BF16)
-    hipLaunchKernelGGL((gemm_fast_kernel<bf16_t>), dim3(grid), dim3(NTHREADS), 0, st, (const char*)x, (const char*)W,
-                       (const char*)bias, esize, (bf16_t*)pre, N, M, d * 2, (int)nlt, (int)ntt, dbg);
+static int grid_for(int64_t ntiles, int cus) { return (int)(ntiles < cus ? ntiles : cus); }
+
+int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_t st) {
+  const int grid = grid_for((int64_t)a.nlt * a.ntt, cus);
+  if (grid <= 0) return CLT_OK;
+  if (filter)
+    hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, 1>), dim3(grid), dim3(NTHREADS), 0, st, a);
+  else if (out_dtype == CLT_BF16)
+    hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, 0>), dim3(grid), dim3(NTHREADS), 0, st, a);
   else
-    hipLaunchKernelGGL((gemm_fast_kernel<float>), dim3(grid), dim3(NTHREADS), 0, st, (const char*)x, (const char*)W,
-                       (const char*)bias, esize, (float*)pre, N, M, d * 2, (int)nlt, (int)ntt, dbg);
+    hipLaunchKernelGGL((gemm_fast_kernel<float, 0>), dim3(grid), dim3(NTHREADS), 0, st, a);
   CLT_CHECK_LAUNCH("clt_encoder_gemm_relu");
   return CLT_OK;
+}
+
+// ---- fused encode + top-k ------------------------------------------------------------------------------------
+FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k) {
+  FusedPlan pl = {};
+  if (!gemm_fast_supported(in_dtype, N, M, d) || out_dtype != CLT_BF16 || k < 1 || k > 256) return pl;
+  // lists hold FUSED_SLOTS entries per 64 latents: keep the expected 64 * k * S / M entries per list under 0.4
+  int64_t S = M / (160 * (int64_t)k);
+  if (S > 16) S = 16;
+  if (S < 2) return pl;
+  const int64_t nlt = (M + GEMM_TM - 1) / GEMM_TM, ntt = (N + GEMM_TN - 1) / GEMM_TN;
+  const int64_t nltA = (nlt + S - 1) / S, nltB = nlt - nltA;
+  if (nltB < 1) return pl;
+  // valid columns of the sample matrix: only its last tile can be W's (partial) last tile
+  const int64_t lastA = (nltA - 1) * S;
+  const int64_t last_valid = (M - lastA * GEMM_TM) < GEMM_TM ? (M - lastA * GEMM_TM) : GEMM_TM;
+  pl.Ls = (nltA - 1) * GEMM_TM + last_valid;
+  if (pl.Ls < k) return pl;
+  pl.S = (int)S;
+  pl.nltA = (int)nltA;
+  pl.nltB = (int)nltB;
+  pl.ntt = (int)ntt;
+  pl.nL = (int)nltB * 4;
+  pl.lds = nltA * GEMM_TM;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+  pl.off_pre_s = take((size_t)N * pl.lds * 2);
+  pl.off_svals = take((size_t)N * k * 2);
+  pl.off_sidx = take((size_t)N * k * 8);
+  pl.off_tau = take((size_t)ntt * GEMM_TN * 4);
+  pl.off_counts = take((size_t)N * pl.nL);
+  pl.off_lists = take((size_t)N * pl.nL * FUSED_SLOTS * 4);
+  pl.bytes = off;
+  pl.ok = true;
+  return pl;
+}
+
+int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, const void* bias, int bias_dtype,
+                             int64_t N, int64_t M, int d, int k, void* out_vals, int64_t* out_idx, char* ws, int* flag,
+                             int cus, int dbg, hipStream_t st) {
+  FastArgs a = {};
+  a.x = (const char*)x;
+  a.W = (const char*)W;
+  a.bias = (const char*)bias;
+  a.bias_esize = bias_dtype == CLT_BF16 ? 2 : 4;
+  a.N = N;
+  a.M = M;
+  a.kbytes = d * 2;
+  a.ntt = pl.ntt;
+  a.lt_S = pl.S;
+  a.dbg = dbg;
+  if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) {
+    set_error("clt_encode_topk_fwd: hipMemsetAsync failed");
+    return CLT_ERR_LAUNCH;
+  }
+  // pass A: every S-th latent tile, stored, and its row top-k -> the token thresholds
+  FastArgs pa = a;
+  pa.nlt = pl.nltA;
+  pa.lt_mode = LT_SAMPLE;
+  pa.pre = ws + pl.off_pre_s;
+  pa.ldp = pl.lds;
+  int rc = launch_gemm_fast(pa, CLT_BF16, false, cus, st);
+  if (rc != CLT_OK) return rc;
+  uint16_t* svals = (uint16_t*)(ws + pl.off_svals);
+  int64_t* sidx = (int64_t*)(ws + pl.off_sidx);
+  rc = topk_rows_gated(ws + pl.off_pre_s, CLT_BF16, pl.lds, nullptr, nullptr, N, pl.Ls, k, svals, CLT_BF16, sidx, nullptr,
+                       st);
+  if (rc != CLT_OK) return rc;
+  float* tau = (float*)(ws + pl.off_tau);
+  const int64_t Npad = (int64_t)pl.ntt * GEMM_TN;
+  hipLaunchKernelGGL(tau_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, svals, k, N, Npad, tau);
+  // pass B: all other tiles, filtered against the thresholds
+  FastArgs pb = a;
+  pb.nlt = pl.nltB;
+  pb.lt_mode = LT_REST;
+  pb.tau = tau;
+  pb.lists = (uint32_t*)(ws + pl.off_lists);
+  pb.counts = (uint8_t*)(ws + pl.off_counts);
+  pb.nL = pl.nL;
+  rc = launch_gemm_fast(pb, CLT_BF16, true, cus, st);
+  if (rc != CLT_OK) return rc;
+  // merge
+  const dim3 grid((unsigned)((N + 3) / 4));
+  if (k <= 64)
+    hipLaunchKernelGGL((fused_select_kernel<1, 4>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
+                       N, M, k, (bf16_t*)out_vals, out_idx, flag);
+  else if (k <= 128)
+    hipLaunchKernelGGL((fused_select_kernel<2, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
+                       N, M, k, (bf16_t*)out_vals, out_idx, flag);
+  else
+    hipLaunchKernelGGL((fused_select_kernel<4, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
+                       N, M, k, (bf16_t*)out_vals, out_idx, flag);
+  CLT_CHECK_LAUNCH("clt_encode_topk_fwd");
+  // gated fallback (a list overflowed): the whole batch the plain way, into the same outputs
+  FastArgs pf = a;
+  pf.nlt = (int)((M + GEMM_TM - 1) / GEMM_TM);
+  pf.lt_mode = LT_ALL;
+  pf.pre = ws;
+  pf.ldp = M;
+  pf.gate = flag;
+  rc = launch_gemm_fast(pf, CLT_BF16, false, cus, st);
+  if (rc != CLT_OK) return rc;
+  return topk_rows_gated(ws, CLT_BF16, M, nullptr, nullptr, N, M, k, out_vals, CLT_BF16, out_idx, flag, st);
 }
 
 }  // namespace clt

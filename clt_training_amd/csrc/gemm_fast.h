@@ -1,5 +1,5 @@
 // Internal interface between encoder_gemm.hip (ABI entry points, generic kernel) and encoder_gemm_fast.hip
-// (the bf16 kernel of the hot path).
+// (the bf16 kernels of the hot path).
 #pragma once
 #include "common.h"
 
@@ -8,6 +8,9 @@ namespace clt {
 constexpr int GEMM_TM = 256;   // latents per tile
 constexpr int GEMM_TN = 256;   // tokens per tile
 constexpr int GEMM_PANEL = 8;  // token tiles per L2 panel
+constexpr int FUSED_SLOTS = 8; // entries per candidate list (64 latents of one token)
+
+enum { LT_ALL = 0, LT_SAMPLE = 1, LT_REST = 2 };
 
 struct TileCoord {
   int64_t lat0, tok0;
@@ -28,12 +31,48 @@ __host__ __device__ __forceinline__ TileCoord tile_of(int64_t id, int64_t nlt, i
   return c;
 }
 
-// true when the fast kernel takes this problem (bf16 operands, K rows a multiple of 64 bytes and at least 4
-// k-steps, bias chunks that cannot straddle the end of the array)
-bool gemm_fast_supported(int in_dtype, int64_t N, int64_t M, int d);
+// Arguments of the fast kernel.  nlt counts VIRTUAL latent tiles: with lt_mode LT_SAMPLE they are every lt_S-th
+// 256-row tile of W, with LT_REST all the others.  Store mode writes virtual tile v to columns [256 v, 256 v + 256)
+// of pre (leading dimension ldp).  Filter mode reads tau and writes lists / counts (nL = 4 * nlt lists per token).
+struct FastArgs {
+  const char* x;
+  const char* W;
+  const char* bias;
+  int bias_esize;
+  void* pre;
+  int64_t ldp;
+  int64_t N, M;
+  int kbytes;
+  int nlt, ntt;
+  int lt_mode, lt_S;
+  const float* tau;
+  uint32_t* lists;
+  uint8_t* counts;
+  int nL;
+  const int* gate;  // if set, the kernel returns at once unless *gate != 0
+  int dbg;
+};
 
-// pre[N, M] = relu(x @ W^T + b); same contract as clt_encoder_gemm_relu.  dbg: timing experiments only.
-int launch_gemm_fast(const void* x, const void* W, const void* bias, int bias_dtype, void* pre, int out_dtype,
-                     int64_t N, int64_t M, int d, int grid, int dbg, hipStream_t st);
+// true when the fast kernel takes this problem (bf16 operands, K rows a multiple of 64 bytes, M a multiple of 8)
+bool gemm_fast_supported(int in_dtype, int64_t N, int64_t M, int d);
+int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_t st);
+
+// Fused encode + top-k without the pre-activation matrix:
+//   pass A  GEMM over every S-th latent tile, stored [N, lds], and clt_topk_rows over it: per token the best k of the
+//           sample and, from its k-th value, a threshold no larger than the k-th value of the whole row;
+//   pass B  GEMM over the other tiles whose epilogue keeps only accumulators that reach the token's threshold;
+//   merge   per token, sample top-k + candidates -> top-k (same key order as clt_topk_rows);
+//   gated fallback: if a candidate list overflowed (flag raised on the device), the plain GEMM + top-k launches
+//           that follow redo the batch; otherwise they return at once.  No host synchronisation anywhere.
+struct FusedPlan {
+  bool ok;
+  int S, nltA, nltB, ntt, nL;
+  int64_t lds, Ls;  // sample matrix: leading dimension and valid columns
+  size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, bytes;
+};
+FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k);
+int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, const void* bias, int bias_dtype,
+                             int64_t N, int64_t M, int d, int k, void* out_vals, int64_t* out_idx, char* ws, int* flag,
+                             int cus, int dbg, hipStream_t st);
 
 }  // namespace clt

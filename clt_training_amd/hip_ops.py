@@ -135,11 +135,12 @@ def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=Non
     nbytes = lib.clt_encode_topk_workspace_bytes(N, M, _DT[out_dtype])
     ws = workspace(x.device, nbytes, "pre")
     b = None if b is None else _c(b)
-    # same two launches as the composite C entry point clt_encode_topk_fwd, issued separately so
-    # that each kernel can be timed on its own (bench.py)
-    pre = ws[:N * M * (2 if out_dtype == torch.bfloat16 else 4)].view(out_dtype).view(N, M)
-    encoder_gemm_relu(x, W, b, out_dtype=out_dtype, out=pre)
-    return topk_rows(pre, k, out_dtype=out_dtype)
+    ov = torch.empty(N, k, dtype=out_dtype, device=x.device)
+    oi = torch.empty(N, k, dtype=torch.int64, device=x.device)
+    # one entry point: the fused sample / filter / merge launches for bf16, GEMM + row top-k otherwise
+    _call("clt_encode_topk_fwd", _ptr(x), _ptr(W), _dt(x), _ptr(b), _dt(b) if b is not None else 0, N, M, d, k,
+          _ptr(ov), _DT[out_dtype], _ptr(oi), _ptr(ws), ws.numel(), _stream(x))
+    return ov, oi
 
 
 # ----------------------------------------------------------------------------- decoder

@@ -200,6 +200,61 @@ def test_encoder_gemm_random(ops):
     torch.testing.assert_close(pre16.float().cpu(), ref16, **BF16)
 
 
+def _plain_encode_topk(ops, x, W, b, k):
+    return ops.topk_rows(ops.encoder_gemm_relu(x, W, b), k)
+
+
+@pytest.mark.parametrize("N,M,d,k,bias", [
+    (8192, 98304, 768, 32, "f32"),      # BASELINE configs[1] layer shape: S = 16
+    (1000, 20488, 128, 32, "bf16"),     # ragged token and latent edges (M % 256 = 8), S = 4
+    (513, 12288, 768, 32, "f32"),       # a tensor-parallel shard of the above: S = 2
+    (300, 65536, 64, 64, None),         # k = 64, no bias
+    (260, 90112, 96, 130, "f32"),       # k > 128: the widest selection state
+])
+def test_fused_encode_topk_equals_plain(ops, N, M, d, k, bias):
+    """clt_encode_topk_fwd's fused path (sample tiles -> thresholds -> filtered GEMM -> merge) must give exactly
+    what GEMM + row top-k give: same accumulators, same key order, so bit-identical values and indices."""
+    g = torch.Generator().manual_seed(N + M + k)
+    x = (torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(M, d, generator=g) / math.sqrt(d)).to(torch.bfloat16).to(DEV)
+    b = None
+    if bias == "f32":
+        b = (0.1 * torch.randn(M, generator=g)).to(DEV)
+    elif bias == "bf16":
+        b = (0.1 * torch.randn(M, generator=g)).to(torch.bfloat16).to(DEV)
+    v_ref, i_ref = _plain_encode_topk(ops, x, W, b, k)
+    v, i = ops.encode_topk(x, W, b, k)
+    assert torch.equal(i, i_ref)
+    assert torch.equal(v, v_ref)
+    if N * M <= 1000 * 20488:  # and the plain pair against the oracle, where that is cheap
+        ref = O.encoder_preacts(x.float().cpu(), W.float().cpu(), None if b is None else b.float().cpu(), torch.bfloat16)
+        sl = O.topk_selection_slack(ref, i.cpu()).max().item()
+        assert sl <= 2.0 ** -5, sl  # near-ties only: accumulation-order differences of one bf16 ulp
+
+
+def test_fused_encode_topk_few_positives_and_overflow(ops):
+    """Rows with fewer than k positive pre-activations (fill rule), and a degenerate batch whose candidate lists
+    overflow (thousands of exact ties at the threshold), which must come out right through the gated fallback."""
+    g = torch.Generator().manual_seed(5)
+    N, M, d, k = 300, 32768, 64, 32
+    x = torch.randn(N, d, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(M, d, generator=g) / 8).to(torch.bfloat16).to(DEV)
+    b = torch.full((M,), -9.0)            # almost nothing survives the ReLU
+    b[torch.randperm(M, generator=g)[:20]] = 3.0
+    b = b.to(DEV)
+    v_ref, i_ref = _plain_encode_topk(ops, x, W, b, k)
+    assert (v_ref == 0).any() and (v_ref > 0).any()
+    v, i = ops.encode_topk(x, W, b, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+    # every latent row identical: all M pre-activations of a token tie
+    W2 = W[:1].expand(M, d).contiguous()
+    v_ref, i_ref = _plain_encode_topk(ops, x, W2, None, k)
+    v, i = ops.encode_topk(x, W2, None, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+    pos = v_ref[:, 0] > 0
+    assert torch.equal(i_ref[pos], torch.arange(k, device=DEV).expand(int(pos.sum()), k))  # lowest-index tie rule
+
+
 # --------------------------------------------------------------------------- FVU
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("masked", [False, True])
