@@ -18,6 +18,8 @@
 //   stage s+1 is certified (counted s_waitcnt vmcnt + s_barrier) early in stage s, one stage before its first
 //   read; the same barrier frees the slot of stage s-1 for the LDS-DMAs of stage s+3.
 // MFMA-bound: 2 * N * M * d flops per launch.
+#include <math.h>
+
 #include "gemm_fast.h"
 #include "topk_select.h"
 
@@ -37,6 +39,7 @@ constexpr int AUX_OFF = 2 * OP_BYTES;     // per stage and wave 1 KiB: [0, 256) 
 constexpr int STAGE_BYTES = 2 * OP_BYTES + 4096;
 constexpr int NTHREADS = 256;
 constexpr int NDMA = 9;                     // LDS-DMAs per wave per stage: 4 W pieces, 4 x pieces, 1 bias/tau piece
+constexpr int QCAP = 512;                    // filter mode: hit-queue entries per wave (4 KiB)
 constexpr int NSTORE = 64;                  // store instructions per wave in the epilogue of an interior tile
 
 #define CLT_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -94,7 +97,7 @@ __host__ __device__ __forceinline__ int lt_actual(int v, int mode, int S) {
 // MODE 0: store relu(pre) (OT = bf16 or f32).  MODE 1: per-token threshold filter, no pre matrix (see FastArgs).
 template <typename OT, int MODE>
 __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE_BYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE_BYTES + (MODE == 1 ? 4 * QCAP * 8 : 0)];
   if (p.gate && *p.gate == 0) return;  // fallback launch: runs only if the fused path raised its flag
   const char* __restrict__ xb = p.x;
   const char* __restrict__ Wb = p.W;
@@ -327,16 +330,30 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
         const int list = (cur_lt * 2 + wm) * 2 + h;
         float tl[4];
         int cnt[4];
-        uint32_t* lp[4];
+        uint32_t lbase[4];  // first entry of the (token, list) list, in entries (host checks that it fits 32 bits)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t tok = tok0 + wn * 128 + j * 32 + r32;
           const float t = *reinterpret_cast<const float*>(cb + AUX_OFF + wave * 1024 + 512 + (j * 32 + r32) * 4);
           tl[j] = tok < N ? t : __builtin_inff();
           cnt[j] = 0;
-          lp[j] = p.lists + (tok * p.nL + list) * FUSED_SLOTS;
+          lbase[j] = (uint32_t)((tok * p.nL + list) * FUSED_SLOTS);
         }
-        int nst = 0;  // store instructions issued (wave-uniform)
+        // Hits go to this wave's LDS queue as (entry index in lists, entry) and leave in whole-wave stores once per
+        // tile: the scan issues no global store, so the counted vmcnt waits of the next k-steps never wait on one.
+        uint2* q = reinterpret_cast<uint2*>(lds + NSTAGE * STAGE_BYTES) + wave * QCAP;
+        int qn = 0;  // wave-uniform
+        auto flush = [&]() {
+          for (int e0 = 0; e0 < qn; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < qn) {
+              const uint2 ent = q[e];
+              if (ent.x != 0xffffffffu && !(dbg & 1)) p.lists[ent.x] = ent.y;
+            }
+          }
+          qn = 0;
+        };
+        if (!(dbg & 2))
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -344,31 +361,40 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
             if (i * 32 + 8 * g < lat_left) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
+                // four independent read + compare pairs, one branch: no compare -> branch latency per element
+                float a[4];
+                unsigned long long m[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const float a = acc_read(acc[i][j][4 * g + q]);
-                  const bool hit = a >= tl[j];
-                  if (__ballot(hit) != 0ull) {
-                    ++nst;
-                    if (hit) {
-                      if (cnt[j] < FUSED_SLOTS && !(dbg & 1))
-                        lp[j][cnt[j]] = (f32_to_bf16_bits(a) << 16) | (uint32_t)(i * 16 + g * 4 + q);
-                      ++cnt[j];
+                for (int qq = 0; qq < 4; ++qq) a[qq] = acc_read(acc[i][j][4 * g + qq]);
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) m[qq] = __ballot(a[qq] >= tl[j]);
+                if (__builtin_expect((m[0] | m[1] | m[2] | m[3]) != 0ull, 0)) {  // out of line: no-hit falls through
+#pragma unroll
+                  for (int qq = 0; qq < 4; ++qq) {
+                    if (m[qq] != 0ull) {
+                      if (a[qq] >= tl[j]) {
+                        const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m[qq] >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m[qq], 0));
+                        q[pos] = make_uint2(cnt[j] < FUSED_SLOTS ? lbase[j] + cnt[j] : 0xffffffffu,
+                                            (f32_to_bf16_bits(a[qq]) << 16) | (uint32_t)(i * 16 + g * 4 + qq));
+                        ++cnt[j];
+                      }
+                      qn += __popcll(m[qq]);
                     }
                   }
+                  if (qn > QCAP - 4 * 64) flush();  // keep room for the next 4 element-instructions (rare)
                 }
               }
             }
             CLT_FENCE();
           }
         }
+        flush();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t tok = tok0 + wn * 128 + j * 32 + r32;
           if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(cnt[j] < 255 ? cnt[j] : 255);
         }
-        stores_behind = 2;
-        wait_allow = NDMA + (nst < 54 ? nst : 54);
       }
       ks = 0;
       if (++t_idx < my_tiles) {
@@ -382,29 +408,32 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing fetches
 }
 
-// tau[tok] = the smallest f32 whose bf16 rounding can reach the k-th best sample value of the token (half a bf16
+// tau[tok] = the smallest f32 whose bf16 rounding can reach the m-th best sample value of the token (half a bf16
 // ulp below it: the rounding interval's lower edge; including the edge itself only adds candidates), or the
-// smallest positive f32 when the sample holds fewer than k positive values.  Padding tokens get +inf.
-__global__ void tau_kernel(const uint16_t* __restrict__ svals, int k, int64_t N, int64_t Npad, float* __restrict__ tau) {
+// smallest positive f32 when the sample holds fewer than m positive values.  Padding tokens get +inf.
+__global__ void tau_kernel(const uint16_t* __restrict__ svals, int k, int m, int64_t N, int64_t Npad,
+                           float* __restrict__ tau) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Npad) return;
   float v = __builtin_inff();
   if (t < N) {
-    const uint32_t bits = (uint32_t)svals[t * k + k - 1] << 16;
+    const uint32_t bits = (uint32_t)svals[t * k + m - 1] << 16;
     v = bits == 0u ? __uint_as_float(1u) : __uint_as_float(bits - 0x8000u);
   }
   tau[t] = v;
 }
 
 // Final selection of the fused path: one wave per token merges the sample's top-k (pass A) with the token's
-// candidate lists (pass B) under the same 64-bit key order as clt_topk_rows, and raises *flag when a list
-// overflowed (the caller's gated fallback launches then redo the token batch the plain way).
+// candidate lists (pass B) under the same 64-bit key order as clt_topk_rows.  The threshold was the sample's m-th
+// value, m <= k: every element of the row that reaches it was collected, so the merged top-k is the row's top-k
+// if and only if its k-th value reaches the threshold too.  If it does not (or a list overflowed), *flag is raised
+// and the caller's gated fallback launches redo the token batch the plain way.
 template <int S, int R>
 __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __restrict__ svals,
                                                            const int64_t* __restrict__ sidx,
                                                            const uint8_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ lists, int nL, int lt_S, int64_t N,
-                                                           int64_t M, int k, bf16_t* __restrict__ out_vals,
+                                                           int64_t M, int k, int m, bf16_t* __restrict__ out_vals,
                                                            int64_t* __restrict__ out_idx, int* __restrict__ flag) {
   constexpr int C = (R - S) * 64;
   __shared__ u64 lds_q[4][C];
@@ -451,8 +480,9 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
       ws.offer(v >= ws.thr_val && v > 0.f, v, col);
     }
   }
-  if (ws.cnt > 0) ws.flush();
-  if (__ballot(over) != 0ull) {
+  ws.flush();
+  const float thr_m = bf16_bits_to_f32(svals[tok * k + m - 1]);
+  if (__ballot(over) != 0ull || ws.thr_val < thr_m) {
     if (lane == 0) atomicOr(flag, 1);
   }
   write_out<S, R>(ws, out_vals, CLT_BF16, tok, out_idx, k);
@@ -499,6 +529,25 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   pl.Ls = (nltA - 1) * GEMM_TM + last_valid;
   if (pl.Ls < k) return pl;
   pl.S = (int)S;
+  // Threshold rank m <= k: the sample's m-th value admits about m * S candidates per token instead of k * S.  The
+  // row then holds fewer than k elements at or above it only if fewer than k - m of them fall outside the sample,
+  // which for exchangeable latents is P(Poisson((k - m) / (S - 1)) >= m) (the sample's m-th value sits where the
+  // row's density is m per sample size): take the smallest m that keeps this under 1e-12 per token.
+  pl.m = k;
+  for (int m = 1; m <= k; ++m) {
+    const double lam = (double)(k - m) / (double)(S - 1);
+    double tail = 0.0;
+    if (lam > 0.0) {
+      // P(X >= m) <= pmf(m) * 1 / (1 - lam / (m + 1)) for lam < m + 1
+      if (lam >= m + 1) continue;
+      const double logp = -lam + m * log(lam) - lgamma((double)m + 1.0);
+      tail = exp(logp) / (1.0 - lam / (m + 1.0));
+    }
+    if (tail < 1e-12) {
+      pl.m = m;
+      break;
+    }
+  }
   pl.nltA = (int)nltA;
   pl.nltB = (int)nltB;
   pl.ntt = (int)ntt;
@@ -550,7 +599,7 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   if (rc != CLT_OK) return rc;
   float* tau = (float*)(ws + pl.off_tau);
   const int64_t Npad = (int64_t)pl.ntt * GEMM_TN;
-  hipLaunchKernelGGL(tau_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, svals, k, N, Npad, tau);
+  hipLaunchKernelGGL(tau_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, svals, k, pl.m, N, Npad, tau);
   // pass B: all other tiles, filtered against the thresholds
   FastArgs pb = a;
   pb.nlt = pl.nltB;
@@ -565,13 +614,13 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   const dim3 grid((unsigned)((N + 3) / 4));
   if (k <= 64)
     hipLaunchKernelGGL((fused_select_kernel<1, 4>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, (bf16_t*)out_vals, out_idx, flag);
+                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
   else if (k <= 128)
     hipLaunchKernelGGL((fused_select_kernel<2, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, (bf16_t*)out_vals, out_idx, flag);
+                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
   else
     hipLaunchKernelGGL((fused_select_kernel<4, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, (bf16_t*)out_vals, out_idx, flag);
+                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
   CLT_CHECK_LAUNCH("clt_encode_topk_fwd");
   // gated fallback (a list overflowed): the whole batch the plain way, into the same outputs
   FastArgs pf = a;

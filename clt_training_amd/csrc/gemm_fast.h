@@ -67,6 +67,7 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 struct FusedPlan {
   bool ok;
   int S, nltA, nltB, ntt, nL;
+  int m;            // rank of the sample value that serves as threshold (<= k)
   int64_t lds, Ls;  // sample matrix: leading dimension and valid columns
   size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, bytes;
 };

@@ -151,7 +151,9 @@ int clt::topk_rows_gated(const void* vals, int val_dtype, int64_t ld, const int6
   const int S = k <= 64 ? 1 : k <= 128 ? 2 : 4;
   const size_t es = dtype_size(val_dtype);
   const bool vec = cand_idx == nullptr && aligned16(vals) && ((size_t)ld * es) % 16 == 0;
-  const bool long_rows = L >= 4096;
+  // four waves per row pay a fixed LDS merge per row: worth it for very long rows, or when there are too few rows
+  // to fill the chip with one wave each
+  const bool long_rows = L >= 32768 || (L >= 4096 && N < 4096);
   hipStream_t st = stream;
   if (val_dtype == CLT_BF16)
     launch_topk_s<bf16_t>(S, long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate);
