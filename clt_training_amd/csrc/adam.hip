@@ -1,20 +1,26 @@
 // Multi-tensor Adam for gfx950: torch.optim.Adam defaults (trainer.py:178-186) over a table of
 // tensors in ONE launch.  One workgroup per chunk of `chunk_elems` elements; 16 B per lane.
 // HBM-bound: algorithmic bytes per parameter = 3 reads (p, m, v) + 1 grad read + 3 writes.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace clt {
 
-template <typename PT, typename GT>
+template <typename PT, typename GT, int VAR>
 __device__ __forceinline__ void adam_chunk(PT* __restrict__ p, const GT* __restrict__ g, PT* __restrict__ m,
                                            PT* __restrict__ v, int64_t n, float step_size, float b1, float b2,
                                            float inv_sqrt_bc2, float eps) {
   constexpr int V = 8;  // elements per thread per pass
   const int64_t nvec = n / V;
-#pragma unroll 4
+#pragma unroll(VAR == 2 ? 1 : 4)
   for (int64_t i = threadIdx.x; i < nvec; i += 256) {
     float pf[V], gf[V], mf[V], vf[V];
-    if constexpr (sizeof(PT) == 2) {
+    if constexpr (sizeof(PT) == 2 && VAR >= 1) {
+      nt_load8(p + i * V, pf);
+      nt_load8(m + i * V, mf);
+      nt_load8(v + i * V, vf);
+    } else if constexpr (sizeof(PT) == 2) {
       Chunk<bf16_t>::load(p + i * V, pf);
       Chunk<bf16_t>::load(m + i * V, mf);
       Chunk<bf16_t>::load(v + i * V, vf);
@@ -30,7 +36,9 @@ __device__ __forceinline__ void adam_chunk(PT* __restrict__ p, const GT* __restr
 #pragma unroll
       for (int q = 0; q < 4; ++q) vf[q] = a[q], vf[q + 4] = b[q];
     }
-    if constexpr (sizeof(GT) == 2) {
+    if constexpr (sizeof(GT) == 2 && VAR >= 1) {
+      nt_load8(g + i * V, gf);
+    } else if constexpr (sizeof(GT) == 2) {
       Chunk<bf16_t>::load(g + i * V, gf);
     } else {
       float a[4], b[4];
@@ -45,7 +53,11 @@ __device__ __forceinline__ void adam_chunk(PT* __restrict__ p, const GT* __restr
       const float denom = sqrtf(vf[q]) * inv_sqrt_bc2 + eps;  // (sqrt(v) / sqrt(bc2)).add_(eps)
       pf[q] = pf[q] - step_size * (mf[q] / denom);            // param.addcdiv_(m, denom, -lr / bc1)
     }
-    if constexpr (sizeof(PT) == 2) {
+    if constexpr (sizeof(PT) == 2 && VAR >= 1) {
+      nt_store8(p + i * V, pf);
+      nt_store8(m + i * V, mf);
+      nt_store8(v + i * V, vf);
+    } else if constexpr (sizeof(PT) == 2) {
       Chunk<bf16_t>::store(p + i * V, pf);
       Chunk<bf16_t>::store(m + i * V, mf);
       Chunk<bf16_t>::store(v + i * V, vf);
@@ -71,6 +83,7 @@ __device__ __forceinline__ void adam_chunk(PT* __restrict__ p, const GT* __restr
   }
 }
 
+template <int VAR>
 __global__ __launch_bounds__(256) void adam_kernel(const clt_adam_tensor* __restrict__ tensors,
                                                    const int32_t* __restrict__ chunk_tensor,
                                                    const int64_t* __restrict__ chunk_start, int chunk_elems,
@@ -86,17 +99,17 @@ __global__ __launch_bounds__(256) void adam_kernel(const clt_adam_tensor* __rest
     bf16_t* m = (bf16_t*)t.m + start;
     bf16_t* v = (bf16_t*)t.v + start;
     if (t.g_dtype == CLT_BF16)
-      adam_chunk<bf16_t, bf16_t>(p, (const bf16_t*)t.g + start, m, v, n, step_size, b1, b2, inv_sqrt_bc2, eps);
+      adam_chunk<bf16_t, bf16_t, VAR>(p, (const bf16_t*)t.g + start, m, v, n, step_size, b1, b2, inv_sqrt_bc2, eps);
     else
-      adam_chunk<bf16_t, float>(p, (const float*)t.g + start, m, v, n, step_size, b1, b2, inv_sqrt_bc2, eps);
+      adam_chunk<bf16_t, float, VAR>(p, (const float*)t.g + start, m, v, n, step_size, b1, b2, inv_sqrt_bc2, eps);
   } else {
     float* p = (float*)t.p + start;
     float* m = (float*)t.m + start;
     float* v = (float*)t.v + start;
     if (t.g_dtype == CLT_BF16)
-      adam_chunk<float, bf16_t>(p, (const bf16_t*)t.g + start, m, v, n, step_size, b1, b2, inv_sqrt_bc2, eps);
+      adam_chunk<float, bf16_t, VAR>(p, (const bf16_t*)t.g + start, m, v, n, step_size, b1, b2, inv_sqrt_bc2, eps);
     else
-      adam_chunk<float, float>(p, (const float*)t.g + start, m, v, n, step_size, b1, b2, inv_sqrt_bc2, eps);
+      adam_chunk<float, float, VAR>(p, (const float*)t.g + start, m, v, n, step_size, b1, b2, inv_sqrt_bc2, eps);
   }
 }
 
@@ -112,8 +125,15 @@ extern "C" int clt_adam_step(const clt_adam_tensor* tensors, int n_tensors, cons
   CLT_CHECK_ARG(chunk_elems > 0 && chunk_elems % 8 == 0, "clt_adam_step: chunk_elems must be a positive multiple of 8");
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunk_tensor,
-                     chunk_start, chunk_elems, lr_factor, b1, b2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+  const char* ve = getenv("CLT_ADAM_VARIANT");  // timing experiments: 0 = cached loads/stores, 2 = no unrolling
+  const int var = ve ? atoi(ve) : 1;
+#define CLT_ADAM_LAUNCH(VARIANT)                                                                                    \
+  hipLaunchKernelGGL(adam_kernel<VARIANT>, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, tensors,    \
+                     chunk_tensor, chunk_start, chunk_elems, lr_factor, b1, b2, eps, (float)(1.0 / bc1),            \
+                     (float)(1.0 / sqrt(bc2)))
+  if (var == 0) CLT_ADAM_LAUNCH(0);
+  else if (var == 2) CLT_ADAM_LAUNCH(2);
+  else CLT_ADAM_LAUNCH(1);
   CLT_CHECK_LAUNCH("clt_adam_step");
   return CLT_OK;
 }

@@ -95,6 +95,22 @@ struct Chunk<float> {
   }
 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Non-temporal 16-byte accesses for streams that are touched once per launch (optimizer state, gradient
+// outputs): they do not displace the lines that ARE reused (gathered rows) from L2 / Infinity Cache.
+__device__ __forceinline__ void nt_load8(const bf16_t* p, float (&f)[8]) {
+  const u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+  f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+}
+__device__ __forceinline__ void nt_store8(bf16_t* p, const float (&f)[8]) {
+  u32x4 u;
+  u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+  u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+  __builtin_nontemporal_store(u, reinterpret_cast<u32x4*>(p));
+}
+
 __device__ __forceinline__ float load_scalar(const void* p, int dtype, int64_t i) {
   if (dtype == CLT_BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
   return reinterpret_cast<const float*>(p)[i];

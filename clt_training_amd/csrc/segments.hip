@@ -42,7 +42,7 @@ __global__ void seg_offsets_kernel(const int32_t* __restrict__ sorted_keys, int3
 template <typename OT, int E>
 __device__ __forceinline__ void store_row_chunk(OT* p, const float (&a)[E]) {
   if constexpr (sizeof(OT) == 2 && E == 8) {
-    Chunk<bf16_t>::store(p, a);
+    nt_store8(p, a);  // the gradient is read back once, by the optimizer, after every other kernel of the step
   } else if constexpr (sizeof(OT) == 4 && E == 4) {
     Chunk<float>::store(p, a);
   } else if constexpr (sizeof(OT) == 4 && E == 8) {

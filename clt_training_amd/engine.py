@@ -199,6 +199,32 @@ class CLTEngine:
     def reset(self):
         self.live = []
 
+    def _keep_input(self, j: int, xn_r: Tensor) -> Tensor:
+        """Layer j's (normalised, local) input as a column block of one [N, L*d] buffer, so that the inputs of the
+        live layers -- a contiguous range of layers -- form one strided matrix for the batched skip GEMMs."""
+        L = len(self.coders)
+        d = xn_r.shape[1]
+        same = all(c.d_in == d and c.W_skips is not None for c in self.coders)
+        if not same or xn_r.dim() != 2:
+            self._xbuf = None
+            return xn_r
+        buf = getattr(self, "_xbuf", None)
+        if buf is None or buf.shape != (xn_r.shape[0], L * d) or buf.dtype != xn_r.dtype or buf.device != xn_r.device:
+            buf = self._xbuf = torch.empty(xn_r.shape[0], L * d, dtype=xn_r.dtype, device=xn_r.device)
+        view = buf[:, j * d:(j + 1) * d]
+        view.copy_(xn_r)
+        return view
+
+    def _live_inputs(self) -> Optional[Tensor]:
+        buf = getattr(self, "_xbuf", None)
+        if buf is None or not self.live:
+            return None
+        layers = [st.layer for st in self.live]
+        if layers != list(range(layers[0], layers[0] + len(layers))):
+            return None
+        d = self.coders[0].d_in
+        return buf[:, layers[0] * d:(layers[-1] + 1) * d]
+
     @torch.no_grad()
     def first_step_init(self, j: int, x_r: Tensor, y_r: Tensor):
         """trainer.py:547-592 on token shards: the means / norms are all-reduced over the group."""
@@ -247,13 +273,16 @@ class CLTEngine:
             cand_i = comm.all_gather_cat1(idx + lat0)
             v, idx = ops.topk_rows(cand_v, k, cand_idx=cand_i)
         N = x_enc.shape[0]
-        me = _Live(j, xn_r.to(cd), x_enc, v, idx, torch.zeros(N, k, dtype=torch.float32, device=v.device))
+        me = _Live(j, self._keep_input(j, xn_r.to(cd)), x_enc, v, idx,
+                   torch.zeros(N, k, dtype=torch.float32, device=v.device))
         self.live.append(me)
         div = max(1, len(self.live) - 1) if cfg.divide_cross_layer else 1  # runner.py:46-49
 
         # ---------------- forward: partial decode of every live source into this target
+        # The skip connections and decoder biases of all live sources (sparse_coder.py:186-190, summed by
+        # runner.py:46-49) are ONE GEMM: the live layers' inputs sit side by side in a persistent [N, L*d] buffer,
+        # so sum_i x_i @ W_skip_i^T = X_live @ cat_i(W_skip_i^T), with 1/div folded into the other sources' blocks.
         P_cur = P_oth = None
-        E_cur = E_oth = None
         for st in self.live:
             li = self.coders[st.layer]
             t = st.slot
@@ -264,16 +293,23 @@ class CLTEngine:
                                        round_acts=li.W_decs[t].dtype == torch.bfloat16, want_acts=True,
                                        lat_begin=li.lat_begin, out=acc_into, accumulate=acc_into is not None)
             st.acts[t] = acts
-            extra = li.b_decs[t].float().unsqueeze(0)
-            if li.W_skips is not None:
-                extra = extra + (st.xn_r @ li.W_skips[t].to(cd).mT).float()  # sparse_coder.py:190
             if is_cur:
-                P_cur, E_cur = out, extra
+                P_cur = out
             else:
                 P_oth = out
-                E_oth = extra if E_oth is None else E_oth + extra
         P = P_cur if P_oth is None else (P_cur + P_oth if div == 1 else P_cur + P_oth / div)
-        E = E_cur if E_oth is None else (E_cur + E_oth if div == 1 else E_cur + E_oth / div)
+        scale = [1.0 if st is me else 1.0 / div for st in self.live]
+        E = sum(self.coders[st.layer].b_decs[st.slot].float() * sc_ for st, sc_ in zip(self.live, scale)).unsqueeze(0)
+        X_live = self._live_inputs()
+        if X_live is not None:
+            Wc = torch.cat([(self.coders[st.layer].W_skips[st.slot].to(cd) * sc_ if sc_ != 1.0 else
+                             self.coders[st.layer].W_skips[st.slot].to(cd)).mT for st, sc_ in zip(self.live, scale)], dim=0)
+            E = E + (X_live @ Wc).float()
+        else:
+            for st, sc_ in zip(self.live, scale):
+                li = self.coders[st.layer]
+                if li.W_skips is not None:
+                    E = E + (st.xn_r @ li.W_skips[st.slot].to(cd).mT).float() * sc_  # sparse_coder.py:190
         yhat_r = comm.reduce_scatter_rows(P).float() + E
         denorm = (lp.out_norm / d**0.5) if cfg.normalize_io else None  # sparse_coder.py:627-630
         if denorm is not None:
@@ -291,14 +327,20 @@ class CLTEngine:
         G = comm.all_gather_rows(G_r)
         G_div = G if div == 1 else (G.float() / div).to(cd)
         G_r_div = G_r if div == 1 else (G_r.float() / div).to(cd)
-        for st in self.live:
+        gb = G_r.sum(0, dtype=torch.float32)  # d b_dec: the same column sums for every live source (x 1/div)
+        gWs = (G_r.mT @ X_live) if X_live is not None else None  # [d, n_live*d]: block i is d W_skip of source i
+        for n_st, st in enumerate(self.live):
             li = self.coders[st.layer]
             t = st.slot
             is_cur = st is me
             Gi, Gi_r = (G, G_r) if is_cur else (G_div, G_r_div)
-            self._acc_grad(li.b_decs[t], Gi_r.sum(0, dtype=torch.float32))
+            self._acc_grad(li.b_decs[t], gb if is_cur or div == 1 else gb / div)
             if li.W_skips is not None:
-                self._acc_grad(li.W_skips[t], (Gi_r.mT @ st.xn_r).float())
+                if gWs is not None:
+                    blk = gWs[:, n_st * d:(n_st + 1) * d]
+                    self._acc_grad(li.W_skips[t], blk if is_cur or div == 1 else blk / div)
+                else:
+                    self._acc_grad(li.W_skips[t], (Gi_r.mT @ st.xn_r).float())
             ps = li.post_enc_scales[t] if li.post_enc_scales is not None else None
             need_pe = li.post_encs[t].requires_grad
             _, e_post, e_scale = ops.decode_bwd_acts(st.idx, st.v, li.W_decs[t], Gi, post_enc=li.post_encs[t],
