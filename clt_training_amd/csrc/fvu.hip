@@ -17,34 +17,43 @@ struct FvuWs {
 };
 
 static int fvu_blocks(int64_t N) {
-  int64_t nb = (N + 63) / 64;
-  if (nb > 128) nb = 128;
+  int64_t nb = (N + 15) / 16;
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
 
 __device__ __forceinline__ float ld(const void* p, int dt, int64_t i) { return load_scalar(p, dt, i); }
 
+// 4 consecutive elements starting at element i (i % 4 == 0, 16-byte aligned base)
+__device__ __forceinline__ void ld4(const void* p, int dt, int64_t i, float (&f)[4]) {
+  if (dt == CLT_BF16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + i);
+    f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+  } else {
+    const float4 u = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+    f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w;
+  }
+}
+
+// grid = (row blocks, column blocks of 1024): four columns per thread, a row block's rows in order
 __global__ __launch_bounds__(256) void fvu_colsum_kernel(const void* __restrict__ y, int y_dtype,
                                                          const uint8_t* __restrict__ mask, int64_t N, int d,
                                                          int64_t rpb, float* __restrict__ pcol,
                                                          float* __restrict__ pcnt) {
-  // grid = (row blocks, column blocks): one column per thread, rows of a block read coalesced across threads
   const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(N, r0 + rpb);
-  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (c < d) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int64_t r = r0;
-    for (; r + 3 < r1; r += 4) {
-      const float m0 = mask ? (mask[r] ? 1.f : 0.f) : 1.f, m1 = mask ? (mask[r + 1] ? 1.f : 0.f) : 1.f;
-      const float m2 = mask ? (mask[r + 2] ? 1.f : 0.f) : 1.f, m3 = mask ? (mask[r + 3] ? 1.f : 0.f) : 1.f;
-      s0 += m0 * ld(y, y_dtype, r * d + c);
-      s1 += m1 * ld(y, y_dtype, (r + 1) * d + c);
-      s2 += m2 * ld(y, y_dtype, (r + 2) * d + c);
-      s3 += m3 * ld(y, y_dtype, (r + 3) * d + c);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; ++r) {
+      const bool m = mask ? mask[r] != 0 : true;
+      float v[4];
+      ld4(y, y_dtype, r * d + c, v);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += m ? v[q] : 0.f;
     }
-    for (; r < r1; ++r) s0 += (mask ? (mask[r] ? 1.f : 0.f) : 1.f) * ld(y, y_dtype, r * d + c);
-    pcol[(int64_t)blockIdx.x * d + c] = (s0 + s1) + (s2 + s3);
+    *reinterpret_cast<float4*>(pcol + (int64_t)blockIdx.x * d + c) = make_float4(s[0], s[1], s[2], s[3]);
   }
   if (blockIdx.y == 0 && threadIdx.x == 0) {
     float cnt = 0.f;
@@ -54,28 +63,40 @@ __global__ __launch_bounds__(256) void fvu_colsum_kernel(const void* __restrict_
 }
 
 __global__ void fvu_total_kernel(const float* __restrict__ psc, int NB, float* __restrict__ out2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float l2 = 0.f, tv = 0.f;
-    for (int b = 0; b < NB; ++b) {
-      l2 += psc[2 * b];
-      tv += psc[2 * b + 1];
-    }
+  // one wave: lane-strided partial sums in a fixed order, then a fixed butterfly
+  float l2 = 0.f, tv = 0.f;
+  for (int b = threadIdx.x; b < NB; b += 64) {
+    l2 += psc[2 * b];
+    tv += psc[2 * b + 1];
+  }
+  l2 = wave_sum(l2);
+  tv = wave_sum(tv);
+  if (threadIdx.x == 0) {
     out2[0] = l2;
     out2[1] = tv;
   }
 }
 
-__global__ void fvu_mean_kernel(const float* __restrict__ pcol, const float* __restrict__ pcnt, int NB, int d,
-                                float* __restrict__ mean) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  float cnt = 0.f;
-  for (int b = 0; b < NB; ++b) cnt += pcnt[b];
-  if (c < d) {
-    float s = 0.f;
-    for (int b = 0; b < NB; ++b) s += pcol[(int64_t)b * d + c];
-    mean[c] = s;  // column SUM; the consumer divides by the (possibly all-reduced) count in mean[d]
+// grid = column blocks of 64: the 4 waves of a block take quarters of the row blocks, then combine in LDS
+__global__ __launch_bounds__(256) void fvu_mean_kernel(const float* __restrict__ pcol, const float* __restrict__ pcnt,
+                                                       int NB, int d, float* __restrict__ mean) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int per = (NB + 3) / 4;
+  const int b0 = w * per, b1 = min(NB, b0 + per);
+  float s = 0.f;
+  if (c < d)
+    for (int b = b0; b < b1; ++b) s += pcol[(int64_t)b * d + c];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < d) mean[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);  // column SUM
+  if (blockIdx.x == 0 && w == 1) {  // the consumer divides by the (possibly all-reduced) count in mean[d]
+    float cnt = 0.f;
+    for (int b = lane; b < NB; b += 64) cnt += pcnt[b];
+    cnt = wave_sum(cnt);
+    if (lane == 0) mean[d] = cnt;
   }
-  if (c == 0) mean[d] = cnt;
 }
 
 __global__ __launch_bounds__(256) void fvu_partial_kernel(const void* __restrict__ y, int y_dtype,
@@ -87,15 +108,22 @@ __global__ __launch_bounds__(256) void fvu_partial_kernel(const void* __restrict
   const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(N, r0 + rpb);
   const float inv_cnt = 1.f / mean[d];
   float l2 = 0.f, tv = 0.f;
-  for (int64_t r = r0; r < r1; ++r) {
-    const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
-    if (m == 0.f) continue;
-    for (int c = threadIdx.x; c < d; c += 256) {
-      const float yy = ld(y, y_dtype, r * d + c);
-      const float e = yy - ld(yhat, yh_dtype, r * d + c);
-      const float dv = yy - mean[c] * inv_cnt;
-      l2 = fmaf(e, e, l2);
-      tv = fmaf(dv, dv, tv);
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const float4 mu4 = *reinterpret_cast<const float4*>(mean + c);
+    const float mu[4] = {mu4.x * inv_cnt, mu4.y * inv_cnt, mu4.z * inv_cnt, mu4.w * inv_cnt};
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; ++r) {
+      const bool m = mask ? mask[r] != 0 : true;
+      float yy[4], yh[4];
+      ld4(y, y_dtype, r * d + c, yy);
+      ld4(yhat, yh_dtype, r * d + c, yh);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float e = m ? yy[q] - yh[q] : 0.f;
+        const float dv = m ? yy[q] - mu[q] : 0.f;
+        l2 = fmaf(e, e, l2);
+        tv = fmaf(dv, dv, tv);
+      }
     }
   }
   l2 = wave_sum(l2);
@@ -124,9 +152,13 @@ __global__ __launch_bounds__(256) void fvu_grad_kernel(const void* __restrict__ 
     l2 = psc[0];
     tv = psc[1];
   }
-  for (int b = 0; b < NB; ++b) {
-    l2 += psc[2 * b];
-    tv += psc[2 * b + 1];
+  if (NB > 0) {  // the same lane-strided order as fvu_total_kernel, in every wave
+    for (int b = threadIdx.x & 63; b < NB; b += 64) {
+      l2 += psc[2 * b];
+      tv += psc[2 * b + 1];
+    }
+    l2 = wave_sum(l2);
+    tv = wave_sum(tv);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     out_scalars[0] = l2 / tv;
@@ -160,7 +192,7 @@ using namespace clt;
 extern "C" size_t clt_fvu_workspace_bytes(int64_t N, int d) {
   if (N <= 0 || d <= 0) return 256;
   const size_t nb = (size_t)fvu_blocks(N);
-  return (nb * (size_t)d + nb + (size_t)d + 1 + 2 * nb + 16) * sizeof(float);
+  return (nb * (size_t)d + nb + (size_t)d + 1 + 2 * nb + 32) * sizeof(float);
 }
 
 extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask,
@@ -181,10 +213,10 @@ extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int
   float* ws = reinterpret_cast<float*>(workspace);
   float* pcol = ws;
   float* pcnt = pcol + (size_t)NB * d;
-  float* mean = pcnt + NB;
-  float* psc = mean + d + 1;
-  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB, (d + 255) / 256), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
-  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
+  float* mean = pcnt + (NB + 3) / 4 * 4;  // float4 loads of the column sums: keep 16-byte alignment
+  float* psc = mean + d + 4;
+  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB, (d + 1023) / 1024), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
+  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 63) / 64), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
                      d, mean);
   hipLaunchKernelGGL(fvu_partial_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d, rpb,
                      (const float*)mean, psc);
@@ -206,6 +238,7 @@ extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int
 extern "C" int clt_fvu_colsum(const void* y, int y_dtype, const uint8_t* mask, int64_t N, int d, float* colsum_count,
                               void* workspace, size_t workspace_bytes, clt_stream_t stream) {
   CLT_CHECK_ARG(y && colsum_count && workspace && N > 0 && d > 0 && valid_dtype(y_dtype), "clt_fvu_colsum: bad argument");
+  CLT_UNSUPPORTED(d % 4 == 0, "clt_fvu_colsum: d=%d must be a multiple of 4", d);
   if (workspace_bytes < clt_fvu_workspace_bytes(N, d)) {
     set_error("clt_fvu_colsum: workspace too small");
     return CLT_ERR_WORKSPACE;
@@ -215,8 +248,8 @@ extern "C" int clt_fvu_colsum(const void* y, int y_dtype, const uint8_t* mask, i
   const int64_t rpb = (N + NB - 1) / NB;
   float* pcol = reinterpret_cast<float*>(workspace);
   float* pcnt = pcol + (size_t)NB * d;
-  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB, (d + 255) / 256), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
-  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
+  hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB, (d + 1023) / 1024), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
+  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 63) / 64), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
                      d, colsum_count);
   CLT_CHECK_LAUNCH("clt_fvu_colsum");
   return CLT_OK;
@@ -227,6 +260,7 @@ extern "C" int clt_fvu_partial(const void* y, int y_dtype, const void* yhat, int
                                size_t workspace_bytes, clt_stream_t stream) {
   CLT_CHECK_ARG(y && yhat && colsum_count && l2tv && workspace && N > 0 && d > 0, "clt_fvu_partial: bad argument");
   CLT_CHECK_ARG(valid_dtype(y_dtype) && valid_dtype(yhat_dtype), "clt_fvu_partial: bad dtype");
+  CLT_UNSUPPORTED(d % 4 == 0, "clt_fvu_partial: d=%d must be a multiple of 4", d);
   if (workspace_bytes < clt_fvu_workspace_bytes(N, d)) {
     set_error("clt_fvu_partial: workspace too small");
     return CLT_ERR_WORKSPACE;
