@@ -15,7 +15,9 @@ import torch
 from . import _lib
 from .hip_ops import _DT, _call, _stream
 
-CHUNK = 1 << 16
+import os
+
+CHUNK = int(os.environ.get("CLT_ADAM_CHUNK", 1 << 14))  # elements per workgroup (a multiple of 8)
 
 
 class Adam(torch.optim.Optimizer):

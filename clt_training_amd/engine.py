@@ -191,6 +191,7 @@ class CLTEngine:
         self.comm = comm or Comm(enabled=False)
         self.live: list[_Live] = []
         self.last_fvu = {}
+        self.last_idx = {}
 
     # ---- helpers
     def _cd(self, lp: ShardedCoder):
@@ -376,6 +377,7 @@ class CLTEngine:
                 still.append(st)
         self.live = still
         self.last_fvu[j] = fvu
+        self.last_idx[j] = idx  # merged global indices (fired-latent bookkeeping, trainer.py:622-628)
         return fvu
 
     @staticmethod

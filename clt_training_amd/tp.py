@@ -83,9 +83,11 @@ class TPTrainer:
             if sae.cfg.normalize_decoder and not cfg.sae.transcode:  # trainer.py:595-596 (row-wise: shard-local)
                 W = sae.W_decs[0]
                 W.data /= W.data.norm(dim=1, keepdim=True) + torch.finfo(W.dtype).eps
-            n_live_before = len(eng.live)
             self.last_fvu[name] = eng.layer_step(j, x, y, mask, acc_steps)
-            del n_live_before
+            # fired-latent bookkeeping on this rank's latent range (trainer.py:622-628)
+            loc = eng.last_idx[j].flatten() - sae.lat_begin
+            loc = loc[(loc >= 0) & (loc < sae.m_local)] if self.comm.world > 1 else loc
+            self.did_fire[name][loc] = True
         self.num_tokens_in_step += n_tok
         step, substep = divmod(self.global_step + 1, cfg.grad_acc_steps)
         if substep == 0:
@@ -99,6 +101,13 @@ class TPTrainer:
                 opt.zero_grad()
             for sch in self.lr_schedulers:
                 sch.step()
+            with torch.no_grad():  # trainer.py:806-816
+                for name, counts in self.num_tokens_since_fired.items():
+                    counts += self.num_tokens_in_step
+                    counts[self.did_fire[name]] = 0
+                self.num_tokens_in_step = 0
+                for fired in self.did_fire.values():
+                    fired.zero_()
         self.global_step += 1
         return self.last_fvu
 

@@ -98,6 +98,16 @@ def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir):
         batch["loss_mask"] = m[rank * Nr:(rank + 1) * Nr]
         f = tr.step(batch)
         fv.append([float(f[h]) for h in hooks])
+        # fired-latent bookkeeping (trainer.py:622-628, 806-816): this rank's latents that fired were reset to 0,
+        # the others aged by the step's global token count
+        for l, h in enumerate(hooks):
+            loc = tr.engine.last_idx[l].flatten() - coders[l].lat_begin
+            loc = loc[(loc >= 0) & (loc < coders[l].m_local)]
+            since = tr.num_tokens_since_fired[h]
+            assert bool((since[loc] == 0).all()) and not bool(tr.did_fire[h].any())
+            quiet = torch.ones_like(since, dtype=torch.bool)
+            quiet[loc] = False
+            assert bool((since[quiet] >= N).all())
     state = {f"{l}.{n}": p.detach().clone() for l, c in enumerate(coders) for n, p in c.named_parameters()}
     torch.save(dict(fvu=fv, state=state), f"{out_dir}/rank{rank}.pt")
     dist.destroy_process_group()
