@@ -85,8 +85,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("CLT_BENCH_REHEARSAL"):  # every rank on GPU 0, gloo on host copies: a functional check of
+            local_rank = 0                          # the multi-rank path on a one-GPU box, not a measurement
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -155,7 +159,7 @@ def main():
         kernels = {}
         dominant, dom_ms = None, -1.0
         for name, (cnt, ms) in prof.summary().items():
-            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_total // world)
+            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_total)
             ent = {"launches_per_step": cnt / args.steps, "mean_ms": round(ms, 4),
                    "ms_per_step": round(ms * cnt / args.steps, 3)}
             if amount is not None:
@@ -187,7 +191,7 @@ def main():
             "config": {"workload": f"GPT-2 small CLT: {L} layers, cross_layer={L}, d={d}, latents={M}, k={k}, "
                                    f"skip_connection, {args.dtype} weights, Adam; {N} tokens/step/GPU "
                                    f"(BASELINE.json configs[1])",
-                       "tokens_per_step": tokens_per_step, "params": P_total, "parallelism": parallelism},
+                       "tokens_per_step": tokens_per_step, "params_per_gpu": P_total, "parallelism": parallelism},
             "fvu_last": round(float(sum(float(v) for v in fv.values()) / len(fv)), 5),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }

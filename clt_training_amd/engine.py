@@ -51,11 +51,14 @@ class Comm:
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.backend = dist.get_backend(group) if self.enabled else "none"
 
+    # gloo (CPU tests, and rehearsals of the multi-rank GPU path on a one-GPU box) works on host copies
     def all_gather_rows(self, t: Tensor) -> Tensor:
         """[n, ...] per rank -> [world * n, ...] (rank-major)."""
         if self.world == 1:
             return t
         t = t.contiguous()
+        if self.backend == "gloo" and t.is_cuda:
+            return self.all_gather_rows(t.cpu()).to(t.device)
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t, group=self.group)
         return out
@@ -74,16 +77,24 @@ class Comm:
             return t
         t = t.contiguous()
         n = t.shape[0] // self.world
-        if self.backend == "gloo":  # gloo has no reduce_scatter: all-reduce and slice (CPU tests only)
-            dist.all_reduce(t, group=self.group)
-            return t[self.rank * n:(self.rank + 1) * n].clone()
+        if self.backend == "gloo":  # gloo has no reduce_scatter: all-reduce and slice
+            h = t.cpu() if t.is_cuda else t
+            if h.dtype == torch.bfloat16:  # gloo sums bf16 in bf16: do it in fp32 like RCCL's accumulate
+                h = h.float()
+            dist.all_reduce(h, group=self.group)
+            return h[self.rank * n:(self.rank + 1) * n].to(device=t.device, dtype=t.dtype).clone()
         out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.reduce_scatter_tensor(out, t, group=self.group)
         return out
 
     def all_reduce_(self, t: Tensor) -> Tensor:
         if self.world > 1:
-            dist.all_reduce(t, group=self.group)
+            if self.backend == "gloo" and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=self.group)
         return t
 
 

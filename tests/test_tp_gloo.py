@@ -72,7 +72,7 @@ def _oracle_layers(saes):
     return layers
 
 
-def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir):
+def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir, device="cpu"):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -81,21 +81,27 @@ def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir):
     from clt_training_amd import TrainConfig
     from clt_training_amd.engine import ShardedCoder
     from clt_training_amd.tp import TPTrainer
-    from oracle import ops_cpu
+    if device == "cpu":
+        from oracle import ops_cpu as ops  # oracle-backed double of hip_ops: test infrastructure
+        adam_cls = ops.Adam
+    else:  # tests/test_gpu_tp2.py: the HIP kernels, both ranks on the one GPU, collectives staged through gloo
+        from clt_training_amd import hip_ops as ops
+        adam_cls = None
 
     saes, steps = _make_problem(sae_kw, L, cross, d, N)
     hooks = [f"h.{i}" for i in range(L)]
     from clt_training_amd import SparseCoderConfig
     cfg = TrainConfig(sae=SparseCoderConfig(**sae_kw), hookpoints=hooks, cross_layer=cross, optimizer="adam", lr=1e-2,
                       lr_warmup_steps=2, finetune="skip-step0-init")
-    coders = [ShardedCoder.from_full(s, rank, world, "cpu") for s in saes]
-    tr = TPTrainer(cfg, [None] * 4, device="cpu", input_widths={h: d for h in hooks}, ops=ops_cpu,
-                   optimizer_cls=ops_cpu.Adam, coders=coders)
+    coders = [ShardedCoder.from_full(s, rank, world, device) for s in saes]
+    tr = TPTrainer(cfg, [None] * 4, device=device, input_widths={h: d for h in hooks}, ops=ops,
+                   optimizer_cls=adam_cls, coders=coders)
     Nr = N // world
     fv = []
     for xs, ys, m in steps:
-        batch = {h: (xs[l][rank * Nr:(rank + 1) * Nr], ys[l][rank * Nr:(rank + 1) * Nr]) for l, h in enumerate(hooks)}
-        batch["loss_mask"] = m[rank * Nr:(rank + 1) * Nr]
+        batch = {h: (xs[l][rank * Nr:(rank + 1) * Nr].to(device), ys[l][rank * Nr:(rank + 1) * Nr].to(device))
+                 for l, h in enumerate(hooks)}
+        batch["loss_mask"] = m[rank * Nr:(rank + 1) * Nr].to(device)
         f = tr.step(batch)
         fv.append([float(f[h]) for h in hooks])
         # fired-latent bookkeeping (trainer.py:622-628, 806-816): this rank's latents that fired were reset to 0,
@@ -108,7 +114,7 @@ def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir):
             quiet = torch.ones_like(since, dtype=torch.bool)
             quiet[loc] = False
             assert bool((since[quiet] >= N).all())
-    state = {f"{l}.{n}": p.detach().clone() for l, c in enumerate(coders) for n, p in c.named_parameters()}
+    state = {f"{l}.{n}": p.detach().cpu().clone() for l, c in enumerate(coders) for n, p in c.named_parameters()}
     torch.save(dict(fvu=fv, state=state), f"{out_dir}/rank{rank}.pt")
     dist.destroy_process_group()
 
@@ -120,14 +126,13 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("case", list(CASES))
-def test_tp2_matches_single_process_oracle(case, tmp_path):
+def run_case(case, tmp_path, device="cpu"):
     from oracle import clt_oracle as O
 
     sae_kw, L, cross = CASES[case]
     d, N, world = 16, 24, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, sae_kw, L, cross, d, N, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, sae_kw, L, cross, d, N, str(tmp_path), device), nprocs=world, join=True)
     res = [torch.load(f"{tmp_path}/rank{r}.pt", weights_only=True) for r in range(world)]
     # ---- single-process oracle: 3 steps of clt_train_step + Adam with the warm-up schedule
     saes, steps = _make_problem(sae_kw, L, cross, d, N)
@@ -171,3 +176,8 @@ def test_tp2_matches_single_process_oracle(case, tmp_path):
                 torch.testing.assert_close(st[f"{l}.post_encs.{i}"], lp.post_encs[i][lo:hi], rtol=1e-4, atol=1e-5)
                 if lp.W_skips[i] is not None:
                     torch.testing.assert_close(st[f"{l}.W_skips.{i}"], lp.W_skips[i], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_tp2_matches_single_process_oracle(case, tmp_path):
+    run_case(case, tmp_path)
