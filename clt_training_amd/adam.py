@@ -34,6 +34,19 @@ class Adam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    def fused_rows(self, p):
+        """State and hyper-parameters with which a gradient-producing kernel may apply THIS step's update of ``p``
+        itself (hip_ops.spt_dense_adam); ``p`` must then reach step() without a .grad.  None if p is not ours."""
+        if not hasattr(self, "_group_of"):
+            self._group_of = {id(q): gi for gi, g in enumerate(self.param_groups) for q in g["params"]}
+        gi = self._group_of.get(id(p))
+        if gi is None:
+            return None
+        st = self._state(p)
+        g = self.param_groups[gi]
+        return dict(m=st["exp_avg"], v=st["exp_avg_sq"], lr=float(g["lr"]), betas=g["betas"], eps=g["eps"],
+                    step=self._step + 1)
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None

@@ -7,6 +7,7 @@
 // segment (they are re-read from L2 / Infinity Cache: dense is only N*d) and writes
 // each output row exactly once -- no atomics, fixed summation order.
 // HBM-bound: algorithmic bytes = M*d*sizeof(out) written + N*k*d*sizeof(dense) gathered.
+#include <math.h>
 #include <string.h>
 
 #include <cstring>
@@ -63,13 +64,39 @@ __device__ __forceinline__ void store_row_chunk(OT* p, const float (&a)[E]) {
 // when the owning row of the next entry changes, the accumulator is stored (zeros for empty rows) and cleared.
 constexpr int RW = 8;
 
-template <typename DT, typename OT, int CH, int U>
+// Optimizer state of the rows for the fused variant (clt_spt_dense_adam): the finished gradient row never goes
+// to memory; it is rounded to the parameter dtype (as the .grad tensor would be) and consumed on the spot by
+// the same update arithmetic as adam.hip.
+struct AdamRows {
+  void* m;
+  void* v;
+  float step_size, b1, b2, inv_sqrt_bc2, eps;
+};
+
+template <typename PT, int E>
+__device__ __forceinline__ void load_row_chunk(const PT* p, float (&a)[E]) {
+  if constexpr (sizeof(PT) == 2 && E == 8) {
+    nt_load8(p, a);
+  } else if constexpr (sizeof(PT) == 4) {
+#pragma unroll
+    for (int q = 0; q < E; q += 4) {
+      const float4 f = *reinterpret_cast<const float4*>(p + q);
+      a[q] = f.x; a[q + 1] = f.y; a[q + 2] = f.z; a[q + 3] = f.w;
+    }
+  } else {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    a[0] = bf16_lo(u.x); a[1] = bf16_hi(u.x); a[2] = bf16_lo(u.y); a[3] = bf16_hi(u.y);
+  }
+}
+
+template <typename DT, typename OT, int CH, int U, bool ADAM>
 __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ offsets, int64_t M,
                                                         const float* __restrict__ vals,
                                                         const void* __restrict__ gate, int gate_dtype,
                                                         const DT* __restrict__ dense, int d, int k,
-                                                        OT* __restrict__ out, float* __restrict__ rowsum) {
+                                                        OT* __restrict__ out, float* __restrict__ rowsum,
+                                                        const AdamRows ad) {
   constexpr int E = Chunk<DT>::E;
   const int lane = threadIdx.x & 63;
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
@@ -94,7 +121,27 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
       for (int c = 0; c < CH; ++c) {
         const int ch = lane + 64 * c;
         if (ch < nchunks) {
-          store_row_chunk<OT, E>(orow + ch * E, acc[c]);
+          if constexpr (ADAM) {
+            OT* mrow = reinterpret_cast<OT*>(ad.m) + (r0 + cur) * (int64_t)d + ch * E;
+            OT* vrow = reinterpret_cast<OT*>(ad.v) + (r0 + cur) * (int64_t)d + ch * E;
+            float pf[E], mf[E], vf[E];
+            load_row_chunk<OT, E>(orow + ch * E, pf);
+            load_row_chunk<OT, E>(mrow, mf);
+            load_row_chunk<OT, E>(vrow, vf);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const float g = sizeof(OT) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+              mf[e] = mf[e] + (g - mf[e]) * (1.f - ad.b1);
+              vf[e] = ad.b2 * vf[e] + (1.f - ad.b2) * g * g;
+              const float denom = sqrtf(vf[e]) * ad.inv_sqrt_bc2 + ad.eps;
+              pf[e] = pf[e] - ad.step_size * (mf[e] / denom);
+            }
+            store_row_chunk<OT, E>(orow + ch * E, pf);
+            store_row_chunk<OT, E>(mrow, mf);
+            store_row_chunk<OT, E>(vrow, vf);
+          } else {
+            store_row_chunk<OT, E>(orow + ch * E, acc[c]);
+          }
 #pragma unroll
           for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
         }
@@ -228,13 +275,13 @@ extern "C" int clt_segments_build(const int64_t* idx, int64_t n, int64_t M, int6
   return CLT_OK;
 }
 
-template <typename DT, typename OT>
+template <typename DT, typename OT, bool ADAM = false>
 static int launch_spt(int ch, dim3 grid, hipStream_t st, const int32_t* perm, const int32_t* offsets, int64_t M,
                       const float* vals, const void* gate, int gate_dtype, const void* dense, int d, int k, void* out,
-                      float* rowsum) {
-#define LAUNCH(CH, U)                                                                                          \
-  hipLaunchKernelGGL((spt_dense_kernel<DT, OT, CH, U>), grid, dim3(256), 0, st, perm, offsets, M, vals, gate,  \
-                     gate_dtype, (const DT*)dense, d, k, (OT*)out, rowsum)
+                      float* rowsum, AdamRows ad = AdamRows()) {
+#define LAUNCH(CH, U)                                                                                                \
+  hipLaunchKernelGGL((spt_dense_kernel<DT, OT, CH, U, ADAM>), grid, dim3(256), 0, st, perm, offsets, M, vals, gate,  \
+                     gate_dtype, (const DT*)dense, d, k, (OT*)out, rowsum, ad)
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
     case 2: LAUNCH(2, 8); break;
@@ -277,6 +324,51 @@ extern "C" int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_
     return rc;
   }
   CLT_CHECK_LAUNCH("clt_spt_dense");
+  return CLT_OK;
+}
+
+extern "C" int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, int64_t M, const float* vals,
+                                  const void* vals_gate, int gate_dtype, const void* dense, int dense_dtype, int d, int k,
+                                  void* p, void* m, void* v, int p_dtype, float* rowsum, float lr, float b1, float b2,
+                                  float eps, int step, clt_stream_t stream) {
+  CLT_CHECK_ARG(perm && offsets && vals && dense && p && m && v, "clt_spt_dense_adam: null pointer");
+  CLT_CHECK_ARG(M > 0 && M < (1ll << 31) && d > 0 && k > 0 && step >= 1, "clt_spt_dense_adam: bad sizes");
+  CLT_CHECK_ARG(valid_dtype(dense_dtype) && valid_dtype(p_dtype) && (!vals_gate || valid_dtype(gate_dtype)),
+                "clt_spt_dense_adam: bad dtype");
+  CLT_CHECK_ARG(aligned16(dense) && aligned16(p) && aligned16(m) && aligned16(v),
+                "clt_spt_dense_adam: pointers must be 16-byte aligned");
+  CLT_UNSUPPORTED(d % 8 == 0 || (d % 4 == 0 && dense_dtype == CLT_F32 && p_dtype == CLT_F32),
+                  "clt_spt_dense_adam: d=%d must be a multiple of 8 (or 4 for all-fp32)", d);
+  const int E = dense_dtype == CLT_BF16 ? 8 : 4;
+  int chunks = d / E, ch = (chunks + 63) / 64;
+  ch = ch <= 1 ? 1 : ch <= 2 ? 2 : ch <= 4 ? 4 : ch <= 8 ? 8 : ch <= 16 ? 16 : -1;
+  CLT_UNSUPPORTED(ch > 0, "clt_spt_dense_adam: d=%d too wide", d);
+  const double bc1 = 1.0 - pow((double)b1, (double)step);  // the same host arithmetic as clt_adam_step
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  AdamRows ad;
+  ad.m = m;
+  ad.v = v;
+  ad.step_size = lr * 1.0f * (float)(1.0 / bc1);
+  ad.b1 = b1;
+  ad.b2 = b2;
+  ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  ad.eps = eps;
+  dim3 grid((unsigned)((M + 4 * RW - 1) / (4 * RW)));
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dense_dtype == CLT_BF16 && p_dtype == CLT_BF16)
+    rc = launch_spt<bf16_t, bf16_t, true>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
+  else if (dense_dtype == CLT_BF16 && p_dtype == CLT_F32)
+    rc = launch_spt<bf16_t, float, true>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
+  else if (dense_dtype == CLT_F32 && p_dtype == CLT_F32)
+    rc = launch_spt<float, float, true>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
+  else
+    rc = launch_spt<float, bf16_t, true>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
+  if (rc != CLT_OK) {
+    set_error("clt_spt_dense_adam: unsupported width");
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_spt_dense_adam");
   return CLT_OK;
 }
 

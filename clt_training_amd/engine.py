@@ -203,6 +203,7 @@ class CLTEngine:
         self.live: list[_Live] = []
         self.last_fvu = {}
         self.last_idx = {}
+        self.fused_opt = None  # an optimizer with fused_rows() (adam.Adam): see _grad_rows
 
     # ---- helpers
     def _cd(self, lp: ShardedCoder):
@@ -360,7 +361,7 @@ class CLTEngine:
                                                      lat_begin=li.lat_begin)
             if st.seg is None:
                 st.seg = ops.segments_build(st.idx, li.m_local, lat_begin=li.lat_begin)
-            self._acc_grad(li.W_decs[t], ops.spt_dense(st.seg, st.acts.pop(t).view(-1), Gi, out_dtype=li.W_decs[t].dtype))
+            self._grad_rows(li.W_decs[t], st.seg, st.acts.pop(t).view(-1), Gi, acc_steps)
             if need_pe:
                 if ps is not None and ps.requires_grad:
                     gp, gs = ops.segment_sum(st.seg, e_post.view(-1), e_scale.view(-1))
@@ -375,21 +376,39 @@ class CLTEngine:
             li = self.coders[st.layer]
             st.slot += 1
             if st.slot >= li.n_slots:
-                gW, gb = ops.spt_dense(st.seg, st.gv.view(-1), st.x_enc, gate=st.v.contiguous().view(-1),
-                                       out_dtype=li.W_enc.dtype, want_rowsum=True)
-                self._acc_grad(li.W_enc, gW)
-                self._acc_grad(li.b_enc, gb.to(li.b_enc.dtype))
                 if not li.cfg.transcode:
                     # SAE: the encoder input is xn - b_dec (sparse_coder.py:637-638): b_dec also gets -sum_n grad_x
+                    # (before W_enc's rows may be updated in place by the fused optimizer step below)
                     gated = st.gv * (st.v > 0)
                     gx = ops.decode_fwd(st.idx, gated, li.W_enc, lat_begin=li.lat_begin, out_dtype=torch.float32)
                     self._acc_grad(li.b_decs[0], -gx.sum(0, dtype=torch.float32))
+                gb = self._grad_rows(li.W_enc, st.seg, st.gv.view(-1), st.x_enc, acc_steps,
+                                     gate=st.v.contiguous().view(-1), want_rowsum=True)
+                self._acc_grad(li.b_enc, gb.to(li.b_enc.dtype))
             else:
                 still.append(st)
         self.live = still
         self.last_fvu[j] = fvu
         self.last_idx[j] = idx  # merged global indices (fired-latent bookkeeping, trainer.py:622-628)
         return fvu
+
+    def _grad_rows(self, p: Tensor, seg, vals: Tensor, dense: Tensor, acc_steps: int, gate: Optional[Tensor] = None,
+                   want_rowsum: bool = False):
+        """Row gradient sparse^T @ dense of a [M_local, d] parameter.  When an optimizer that can take it is attached
+        (self.fused_opt) and this is the step's only contribution, the rows go straight into the Adam update and
+        no .grad is materialised; otherwise into p.grad.  Returns the row sums if asked."""
+        fo = self.fused_opt
+        if fo is not None and acc_steps == 1 and p.grad is None and hasattr(self.ops, "spt_dense_adam"):
+            h = fo.fused_rows(p)
+            if h is not None:
+                return self.ops.spt_dense_adam(seg, vals, dense, p.data, h["m"], h["v"], lr=h["lr"], betas=h["betas"],
+                                               eps=h["eps"], step=h["step"], gate=gate, want_rowsum=want_rowsum)
+        if want_rowsum:
+            gW, rs = self.ops.spt_dense(seg, vals, dense, gate=gate, out_dtype=p.dtype, want_rowsum=True)
+        else:
+            gW, rs = self.ops.spt_dense(seg, vals, dense, gate=gate, out_dtype=p.dtype), None
+        self._acc_grad(p, gW)
+        return rs
 
     @staticmethod
     def _acc_grad(p: Tensor, g: Tensor):

@@ -220,6 +220,22 @@ def spt_dense(seg: Segments, vals: Tensor, dense: Tensor, *, gate: Optional[Tens
     return (out, rowsum) if want_rowsum else out
 
 
+def spt_dense_adam(seg: Segments, vals: Tensor, dense: Tensor, p: Tensor, m: Tensor, v: Tensor, *, lr: float,
+                   betas, eps: float, step: int, gate: Optional[Tensor] = None, want_rowsum: bool = False):
+    """spt_dense whose rows feed the Adam update of (p, m, v) directly (clt_spt_dense_adam)."""
+    vals, dense = _c(vals), _c(dense)
+    assert vals.dtype == torch.float32 and vals.numel() == seg.perm.numel()
+    d = dense.shape[1]
+    assert p.shape == (seg.M, d) and p.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    assert m.dtype == p.dtype and v.dtype == p.dtype and m.shape == p.shape and v.shape == p.shape
+    rowsum = torch.empty(seg.M, dtype=torch.float32, device=dense.device) if want_rowsum else None
+    gate = None if gate is None else _c(gate)
+    _call("clt_spt_dense_adam", _ptr(seg.perm), _ptr(seg.offsets), seg.M, _ptr(vals), _ptr(gate),
+          _dt(gate) if gate is not None else 0, _ptr(dense), _dt(dense), d, seg.k, _ptr(p), _ptr(m), _ptr(v), _dt(p),
+          _ptr(rowsum), float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), _stream(dense))
+    return rowsum
+
+
 def segment_sum(seg: Segments, a: Tensor, b: Optional[Tensor] = None):
     a = _c(a)
     assert a.dtype == torch.float32

@@ -5,6 +5,8 @@ construction rule, Adam groups + LR rule, warm-up schedule, step-0 init and step
 (sparsify/__main__.py:173-177)."""
 from __future__ import annotations
 
+import os
+
 from dataclasses import replace
 from typing import Optional
 
@@ -59,6 +61,11 @@ class TPTrainer:
                for sae in self.saes.values()]  # trainer.py:166-173: the FULL latent count sets the LR
         adam = (optimizer_cls or Adam)(pgs, betas=(cfg.b1, cfg.b2))
         self.optimizers = [adam]
+        # Decoder / encoder row gradients go straight into the optimizer update (no .grad round trip) when nothing
+        # else consumes them: one micro-step per optimizer step, and no projection of the decoder gradient.
+        fuse = (hasattr(adam, "fused_rows") and cfg.grad_acc_steps * cfg.micro_acc_steps == 1
+                and not (cfg.sae.normalize_decoder and not cfg.sae.transcode) and not os.environ.get("CLT_NO_FUSED_ADAM"))
+        self.engine.fused_opt = adam if fuse else None
         self.lr_schedulers = [WarmupLinearSchedule(adam, cfg.lr_warmup_steps, num_batches)]
         self.global_step = 0
         self.num_tokens_since_fired = {h: torch.zeros(s.m_local, device=self.device, dtype=torch.long)
@@ -87,7 +94,7 @@ class TPTrainer:
             # fired-latent bookkeeping on this rank's latent range (trainer.py:622-628)
             loc = eng.last_idx[j].flatten() - sae.lat_begin
             loc = loc[(loc >= 0) & (loc < sae.m_local)] if self.comm.world > 1 else loc
-            self.did_fire[name][loc] = True
+            self.did_fire[name].index_fill_(0, loc, True)
         self.num_tokens_in_step += n_tok
         step, substep = divmod(self.global_step + 1, cfg.grad_acc_steps)
         if substep == 0:
@@ -104,7 +111,7 @@ class TPTrainer:
             with torch.no_grad():  # trainer.py:806-816
                 for name, counts in self.num_tokens_since_fired.items():
                     counts += self.num_tokens_in_step
-                    counts[self.did_fire[name]] = 0
+                    counts.masked_fill_(self.did_fire[name], 0)  # no host sync, unlike counts[mask] = 0
                 self.num_tokens_in_step = 0
                 for fired in self.did_fire.values():
                     fired.zero_()

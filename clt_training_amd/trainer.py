@@ -164,7 +164,7 @@ class Trainer:
             with torch.no_grad():
                 for name, counts in self.num_tokens_since_fired.items():
                     counts += self.num_tokens_in_step
-                    counts[self.did_fire[name]] = 0
+                    counts.masked_fill_(self.did_fire[name], 0)  # no host sync, unlike counts[mask] = 0
                 self.num_tokens_in_step = 0
                 for mask in self.did_fire.values():
                     mask.zero_()

@@ -131,6 +131,19 @@ int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_t M, const 
                   int gate_dtype, const void* dense, int dense_dtype, int d, int k, void* out, int out_dtype,
                   float* rowsum, clt_stream_t stream);
 
+/* clt_spt_dense with the optimizer step applied to each finished row, for steps in which the gradient has no
+ * other consumer (grad_acc_steps == 1, no clipping): the fusion of the dense grad-W write of xformers.py:179-231 /
+ * fused_encoder.py:150-155 with the torch.optim.Adam update of trainer.py:178-186,797-802 for that tensor.
+ *   g = round_to(p_dtype, sum_{e in segment r} vals[e] * dense[e / k, :])   (what .grad would have held)
+ *   m, v, p updated exactly as clt_adam_step does (lr is the group's current lr; step is 1-based).
+ * p, m, v [M,d] `p_dtype`, updated in place; the gradient row never reaches memory (4 of the 16 bytes per
+ * parameter that grad write + Adam move).  rowsum as in clt_spt_dense.  Bitwise equal to clt_spt_dense followed
+ * by clt_adam_step.                                                                                            */
+int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, int64_t M, const float* vals, const void* vals_gate,
+                       int gate_dtype, const void* dense, int dense_dtype, int d, int k, void* p, void* m, void* v,
+                       int p_dtype, float* rowsum, float lr, float b1, float b2, float eps, int step,
+                       clt_stream_t stream);
+
 /* Per-latent sums of up to two per-entry arrays (post_enc / post_enc_scale grads: the
  * scatter-adds autograd generates for sparse_coder.py:136-140):
  *   out_a[r] = sum_{e in segment r} a[e];  out_b likewise (b/out_b may be NULL).  fp32.  */

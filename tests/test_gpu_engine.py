@@ -143,3 +143,56 @@ def test_engine_tp1_vs_oracle(case):
             torch.testing.assert_close(c.W_decs[i].detach().cpu(), lp.W_decs[i], rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(c.b_decs[i].detach().cpu(), lp.b_decs[i], rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(c.post_encs[i].detach().cpu(), lp.post_encs[i], rtol=1e-4, atol=1e-5)
+
+
+def test_fused_row_adam_equals_grad_then_adam(monkeypatch):
+    """clt_spt_dense_adam (row gradients consumed by the optimizer update in the same kernel) against the two-kernel
+    route clt_spt_dense -> .grad -> clt_adam_step: every parameter bit-identical after 3 bf16 train steps."""
+    import sys
+    sys.path.insert(0, "tests")
+    from clt_training_amd import SparseCoderConfig, TrainConfig
+    from clt_training_amd.tp import TPTrainer
+
+    L, d, N, k = 3, 64, 512, 8
+    hooks = [f"h.{i}" for i in range(L)]
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for s in range(3):
+        b = {}
+        for h in hooks:
+            x = torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)
+            b[h] = (x.bfloat16().to(DEV), (0.5 * x + 0.5 * torch.randn(N, d, generator=g)).bfloat16().to(DEV))
+        b["loss_mask"] = (torch.rand(N, generator=g) > 0.1).to(DEV)
+        batches.append(b)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("CLT_NO_FUSED_ADAM", raising=False)
+        else:
+            monkeypatch.setenv("CLT_NO_FUSED_ADAM", "1")
+        torch.manual_seed(0)
+        cfg = TrainConfig(sae=SparseCoderConfig(dtype="bfloat16", expansion_factor=32, k=k, transcode=True,
+                                                skip_connection=True, post_encoder_scale=True),
+                          hookpoints=list(hooks), cross_layer=L, optimizer="adam", lr=1e-3, lr_warmup_steps=1,
+                          log_to_wandb=False)
+        tr = TPTrainer(cfg, batches, device=DEV, num_batches=10)
+        assert (tr.engine.fused_opt is not None) == fused
+        with torch.no_grad():
+            gg = torch.Generator(device=DEV).manual_seed(1)
+            for sae in tr.saes.values():
+                for n, p in sae.named_parameters():
+                    if n.startswith("W_dec"):
+                        p.copy_((0.05 * torch.randn(p.shape, generator=gg, device=DEV)).to(p.dtype))
+        fv = [tr.step(b) for b in batches]
+        params = {f"{h}.{n}": p.detach().clone() for h, sae in tr.saes.items() for n, p in sae.named_parameters()}
+        return fv, params
+
+    fv_a, pa = run(True)
+    fv_b, pb = run(False)
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
+    for a, b in zip(fv_a, fv_b):
+        for h in hooks:
+            assert float(a[h]) == float(b[h])
+    moved = [n for n in pa if "W_decs" in n or n.endswith("W_enc")]
+    assert moved
