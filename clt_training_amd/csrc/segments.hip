@@ -114,20 +114,58 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
   float rs = 0.f;   // wave-uniform row sum
   int cur = 0;      // row (relative to r0) being accumulated
 
+  // Fused optimizer variant: the parameter / exp_avg / exp_avg_sq chunks of the row being accumulated are fetched
+  // when the row STARTS (16 bytes per lane and chunk each), so they are in flight behind the row's gathers and
+  // the next row's fetch is issued before the current row's update arithmetic.
+  constexpr bool PREFETCH = ADAM && sizeof(OT) * E == 16;
+  u32x4 pq[PREFETCH ? CH : 1], mq[PREFETCH ? CH : 1], vq[PREFETCH ? CH : 1];
+  auto prefetch_chunk = [&](int row, int c) {
+    if constexpr (PREFETCH) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) {
+        const int64_t off = (r0 + row) * (int64_t)d + ch * E;
+        pq[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(out + off));
+        mq[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const OT*>(ad.m) + off));
+        vq[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const OT*>(ad.v) + off));
+      }
+    }
+  };
+  auto unpack = [&](const u32x4& u, float (&f)[E]) {
+    if constexpr (sizeof(OT) == 2) {
+      f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+      if constexpr (E == 8) {
+        f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+      }
+    } else {
+      f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < CH; ++c) prefetch_chunk(0, c);
+
   auto flush_until = [&](int upto) {  // store rows cur .. upto-1 (wave-uniform loop)
     while (cur < upto) {
       OT* orow = out + (r0 + cur) * (int64_t)d;
+      if constexpr (ADAM) {
+        const bool more = cur + 1 < nrows;  // wave-uniform
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int ch = lane + 64 * c;
-        if (ch < nchunks) {
-          if constexpr (ADAM) {
-            OT* mrow = reinterpret_cast<OT*>(ad.m) + (r0 + cur) * (int64_t)d + ch * E;
-            OT* vrow = reinterpret_cast<OT*>(ad.v) + (r0 + cur) * (int64_t)d + ch * E;
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            const int64_t off = (r0 + cur) * (int64_t)d + ch * E;
+            OT* mrow = reinterpret_cast<OT*>(ad.m) + off;
+            OT* vrow = reinterpret_cast<OT*>(ad.v) + off;
             float pf[E], mf[E], vf[E];
-            load_row_chunk<OT, E>(orow + ch * E, pf);
-            load_row_chunk<OT, E>(mrow, mf);
-            load_row_chunk<OT, E>(vrow, vf);
+            if constexpr (PREFETCH) {
+              unpack(pq[c], pf);
+              unpack(mq[c], mf);
+              unpack(vq[c], vf);
+              if (more) prefetch_chunk(cur + 1, c);  // the next row's chunk, behind this row's arithmetic
+            } else {
+              load_row_chunk<OT, E>(orow + ch * E, pf);
+              load_row_chunk<OT, E>(mrow, mf);
+              load_row_chunk<OT, E>(vrow, vf);
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
               const float g = sizeof(OT) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
@@ -135,15 +173,22 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
               vf[e] = ad.b2 * vf[e] + (1.f - ad.b2) * g * g;
               const float denom = sqrtf(vf[e]) * ad.inv_sqrt_bc2 + ad.eps;
               pf[e] = pf[e] - ad.step_size * (mf[e] / denom);
+              acc[c][e] = 0.f;
             }
             store_row_chunk<OT, E>(orow + ch * E, pf);
             store_row_chunk<OT, E>(mrow, mf);
             store_row_chunk<OT, E>(vrow, vf);
-          } else {
-            store_row_chunk<OT, E>(orow + ch * E, acc[c]);
           }
+        }
+      } else {
 #pragma unroll
-          for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            store_row_chunk<OT, E>(orow + ch * E, acc[c]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+          }
         }
       }
       if (rowsum && lane == 0) rowsum[r0 + cur] = rs;
@@ -284,7 +329,10 @@ static int launch_spt(int ch, dim3 grid, hipStream_t st, const int32_t* perm, co
                      gate_dtype, (const DT*)dense, d, k, (OT*)out, rowsum, ad)
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
-    case 2: LAUNCH(2, 8); break;
+    case 2:
+      if (ADAM) LAUNCH(2, 4);  // fewer gathers in flight, more waves: the state streams need the occupancy
+      else LAUNCH(2, 8);
+      break;
     case 4: LAUNCH(4, 4); break;
     case 8: LAUNCH(8, 2); break;
     case 16: LAUNCH(16, 1); break;
