@@ -131,6 +131,9 @@ def main():
                 elif n.startswith("post_encs"):
                     p.copy_(0.01 * torch.randn(p.shape, generator=g, device=device))
     P_total = sum(p.numel() for sae in trainer.saes.values() for p in sae.parameters())
+    # parameters that still go through clt_adam_step: everything but the [M, d] matrices when their update is fused
+    fused = getattr(getattr(trainer, "engine", None), "fused_opt", None) is not None
+    P_adam = sum(p.numel() for sae in trainer.saes.values() for p in sae.parameters() if not (fused and p.dim() == 2 and p.shape[0] > d))
 
     def barrier():
         if world > 1:
@@ -162,7 +165,7 @@ def main():
         kernels = {}
         dominant, dom_ms = None, -1.0
         for name, (cnt, ms) in prof.summary().items():
-            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_total)
+            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_adam)
             ent = {"launches_per_step": cnt / args.steps, "mean_ms": round(ms, 4),
                    "ms_per_step": round(ms * cnt / args.steps, 3)}
             if amount is not None:
@@ -177,9 +180,15 @@ def main():
         roofline = None
         if dominant:
             e = kernels[dominant]
+            # HBM bytes per launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs at these
+            # layer shapes; counters cannot be read from inside this process)
+            traffic = None
+            pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
+            if pmc.exists() and world == 1 and (N, d, M, k, es) == (8192, 768, 98304, 32, 2):
+                traffic = json.loads(pmc.read_text())["kernels"].get(dominant, {}).get("hbm_bytes")
             roofline = {"kernel": dominant, "bound": e["bound"], "achieved": e["achieved"],
                         "peak": 2500.0 if e["bound"] == "mfma" else 8000.0, "unit": e["unit"], "frac": e["frac"],
-                        "traffic": None}
+                        "traffic": traffic}
         cpu = None
         if not args.no_cpu_baseline:
             sys.path.insert(0, str(ROOT))
