@@ -440,8 +440,9 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
   if (tok >= N) return;
-  WaveSelect<S, R> ws;
+  WaveSelect<S, R, (S <= 2)> ws;
   ws.init(lds_q[wave], lane, k);
+  ws.set_bits(48, 32 - __clz((int)(M > 1 ? M - 1 : 1)));  // bf16 values, latent indices < M
   // the sample's best k: column c of the sample matrix is latent (c / 256) * S * 256 + c % 256
   for (int e0 = 0; e0 < k; e0 += 64) {
     const int e = e0 + lane;
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
   if (__ballot(over) != 0ull || ws.thr_val < thr_m) {
     if (lane == 0) atomicOr(flag, 1);
   }
+  ws.finalize();
   write_out<S, R>(ws, out_vals, CLT_BF16, tok, out_idx, k);
 }
 

@@ -31,8 +31,10 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const VT* __restrict__ v
   const int part = WPR == 4 ? wave : 0;
   if (WPR == 1 && row >= N) return;
 
-  WaveSelect<S, R> ws;
+  constexpr bool RX = WPR == 1 && S <= 2;  // radix flush for one wave per row; the 4-wave LDS merge keeps sorted lists
+  WaveSelect<S, R, RX> ws;
   ws.init(lds_q[wave], lane, k);
+  ws.set_bits(sizeof(VT) == 2 ? 48 : 32, cand_idx ? 32 : 32 - __clz((int)(L > 1 ? L - 1 : 1)));
 
   int64_t len = counts ? (int64_t)counts[row] : L;
   if (len > L) len = L;
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const VT* __restrict__ v
       write_out<S, R>(ws, out_vals, out_dtype, row, out_idx, k);
     }
   } else {
+    ws.finalize();
     write_out<S, R>(ws, out_vals, out_dtype, row, out_idx, k);
   }
 }

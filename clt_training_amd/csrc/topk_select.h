@@ -70,8 +70,13 @@ __device__ __forceinline__ u64 make_key(float v, unsigned col) {
   return ((u64)bits << 32) | (u64)(~col);
 }
 
-// Per-wave selection state.
-template <int S, int R>
+// Per-wave selection state.  key[0, S) hold the best S*64 keys seen so far, key[S, R) receive the queue on a flush.
+// RX = false: a flush is one bitonic sort of all 64*R keys (the list stays sorted).
+// RX = true : a flush finds the k-th largest key by a most-significant-bit-first search over the bits that can
+//             differ (value bits [vlo, 62] and index bits [0, lob): one v_cmp_ge_u64 + s_bcnt1 per register and
+//             bit, ~5x fewer instructions than the sort), keeps the k survivors UNSORTED, and finalize() orders
+//             them once at the end by counting ranks through LDS.  Needs 2*S*64 <= C (S <= 2).
+template <int S, int R, bool RX = false>
 struct WaveSelect {
   static constexpr int C = (R - S) * 64;  // queue capacity
   u64 key[R];
@@ -80,6 +85,7 @@ struct WaveSelect {
   int cnt;
   volatile u64* q;  // this wave's LDS queue [C]
   int lane, k;
+  int vlo, lob, nsel;
 
   __device__ __forceinline__ void init(volatile u64* queue, int lane_, int k_) {
 #pragma unroll
@@ -90,6 +96,15 @@ struct WaveSelect {
     q = queue;
     lane = lane_;
     k = k_;
+    vlo = 32;
+    lob = 32;
+    nsel = 0;
+  }
+  // value_low_bit: 48 when every value is a bf16 (low 16 bits of the f32 pattern are zero), else 32;
+  // index_bits: every column index is < 2^index_bits
+  __device__ __forceinline__ void set_bits(int value_low_bit, int index_bits) {
+    vlo = value_low_bit;
+    lob = index_bits;
   }
 
   __device__ __forceinline__ void flush() {
@@ -101,10 +116,74 @@ struct WaveSelect {
       key[r] = e < cnt ? q[e] : 0ull;
     }
     __builtin_amdgcn_wave_barrier();
-    bitonic_sort_desc<R>(key, lane);
-    thr_key = element_at<R>(key, k - 1);
+    if constexpr (!RX) {
+      bitonic_sort_desc<R>(key, lane);
+      thr_key = element_at<R>(key, k - 1);
+    } else {
+      int nz = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) nz += __popcll(__ballot(key[r] != 0ull));
+      u64 T = 1ull;  // fewer than k real keys: keep them all
+      if (nz >= k) {
+        // invariant: at least k keys are >= prefix.  Index bits [lob, 32) are ones in every real key.
+        u64 prefix = lob < 32 ? (1ull << 32) - (1ull << lob) : 0ull;
+        auto step = [&](int b) {
+          const u64 t = prefix | (1ull << b);
+          int c = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) c += __popcll(__ballot(key[r] >= t));
+          if (c >= k) prefix = t;
+        };
+        for (int b = 62; b >= vlo; --b) step(b);
+        for (int b = lob - 1; b >= 0; --b) step(b);
+        T = prefix;  // the k-th largest key (keys are distinct)
+      }
+      int base = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool sel = key[r] >= T;
+        const u64 m = __ballot(sel);
+        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (sel) q[pos] = key[r];
+        base += __popcll(m);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int e = r * 64 + lane;
+        key[r] = (r < S && e < base) ? q[e] : 0ull;
+      }
+      __builtin_amdgcn_wave_barrier();
+      nsel = base;
+      thr_key = nz >= k ? T : 0ull;
+    }
     thr_val = __uint_as_float((unsigned)(thr_key >> 32));
     cnt = 0;
+  }
+
+  // Order the survivors (largest first).  Call after the last flush, before write_out.
+  __device__ __forceinline__ void finalize() {
+    if constexpr (RX) {
+      static_assert(2 * S * 64 <= C, "rank buffer does not fit the queue");
+      // q[0, nsel) still holds the survivors (written by the last flush): rank = number of larger keys
+      int rank[S];
+#pragma unroll
+      for (int r = 0; r < S; ++r) rank[r] = 0;
+      for (int j = 0; j < nsel; ++j) {
+        const u64 o = q[j];  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int r = 0; r < S; ++r) rank[r] += o > key[r] ? 1 : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < S; ++r)
+        if (r * 64 + lane < nsel) q[S * 64 + rank[r]] = key[r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < S; ++r) key[r] = r * 64 + lane < nsel ? q[S * 64 + r * 64 + lane] : 0ull;
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 
   // Offer one candidate per lane.  `cand` = this lane holds a possible candidate.
@@ -141,8 +220,8 @@ __device__ __forceinline__ void store_val(void* base, int dtype, int64_t i, floa
 
 // Write the k best of a finished selection; complete short rows (fewer than k
 // candidates) with (0, lowest unselected column numbers).
-template <int S, int R>
-__device__ __forceinline__ void write_out(WaveSelect<S, R>& ws, void* out_base, int out_dtype, int64_t row,
+template <int S, int R, bool RX>
+__device__ __forceinline__ void write_out(WaveSelect<S, R, RX>& ws, void* out_base, int out_dtype, int64_t row,
                                           int64_t* out_idx, int k) {
   const int64_t ob = row * k;
   out_idx += ob;

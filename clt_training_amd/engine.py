@@ -312,12 +312,16 @@ class CLTEngine:
                 P_oth = out
         P = P_cur if P_oth is None else (P_cur + P_oth if div == 1 else P_cur + P_oth / div)
         scale = [1.0 if st is me else 1.0 / div for st in self.live]
-        E = sum(self.coders[st.layer].b_decs[st.slot].float() * sc_ for st, sc_ in zip(self.live, scale)).unsqueeze(0)
+        bs = torch.stack([self.coders[st.layer].b_decs[st.slot].float() for st in self.live])  # [n_live, d]
+        if div != 1:
+            bs = bs * torch.tensor(scale, dtype=torch.float32, device=bs.device).unsqueeze(1)
+        E = bs.sum(0, keepdim=True)
         X_live = self._live_inputs()
         if X_live is not None:
-            Wc = torch.cat([(self.coders[st.layer].W_skips[st.slot].to(cd) * sc_ if sc_ != 1.0 else
-                             self.coders[st.layer].W_skips[st.slot].to(cd)).mT for st, sc_ in zip(self.live, scale)], dim=0)
-            E = E + (X_live @ Wc).float()
+            Ws = torch.cat([self.coders[st.layer].W_skips[st.slot].mT for st in self.live], dim=0)  # [n_live*d, d]
+            if div != 1:
+                Ws = Ws * torch.tensor(scale, dtype=Ws.dtype, device=Ws.device).repeat_interleave(d).unsqueeze(1)
+            E = E + (X_live @ Ws.to(cd)).float()
         else:
             for st, sc_ in zip(self.live, scale):
                 li = self.coders[st.layer]
