@@ -45,6 +45,32 @@ def synth_batches(hooks, N, d, n_batches, dtype, device, seed=0):
     return out
 
 
+class SimComm:
+    """Per-rank COMPUTE rehearsal of a tp-way run on one GPU (--simulate-tp W): this process does what rank 0 of a
+    W-rank group does, with every collective replaced by a local stand-in of the same shapes (all-gather = rolled
+    copies, so tokens and candidates differ per pretend rank; reduce-scatter = a slice; all-reduce = identity).
+    The arithmetic results are meaningless and no RCCL time is included: it sizes kernels at their tp shapes, it is
+    not a measurement of the metric."""
+
+    def __init__(self, world, m_local):
+        self.enabled, self.group, self.world, self.rank, self.backend, self.m_local = True, None, world, 0, "sim", m_local
+
+    def all_gather_rows(self, t):
+        return torch.cat([t.roll(37 * r, 0) for r in range(self.world)], 0)
+
+    def all_gather_cat1(self, t):
+        parts = [t.roll(37 * r, 0) for r in range(self.world)]
+        if t.dtype == torch.int64:  # global candidate indices: pretend rank r owns [r * m_local, (r + 1) * m_local)
+            parts = [p + r * self.m_local for r, p in enumerate(parts)]
+        return torch.cat(parts, 1).contiguous()
+
+    def reduce_scatter_rows(self, t):
+        return t[: t.shape[0] // self.world].clone()
+
+    def all_reduce_(self, t):
+        return t
+
+
 def algorithmic_work(name, N, d, M, k, es, P_total):
     """Algorithmic flops / bytes per launch -> (amount, 'flop'|'byte')."""
     if name in ("clt_encoder_gemm_relu", "clt_encode_topk_fwd"):  # the fused call is priced as its GEMM alone
@@ -79,6 +105,9 @@ def main():
     ap.add_argument("--path", default="engine", choices=["engine", "autograd"],
                     help="engine: explicit CLTEngine (also the multi-GPU path); autograd: SparseCoder/CrossLayerRunner")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--simulate-tp", type=int, default=0,
+                    help="rehearse rank 0's compute of a W-rank run on one GPU (collectives are local stand-ins; "
+                         "NOT a measurement of the metric: the line is marked 'simulated')")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,8 +143,11 @@ def main():
         from clt_training_amd.tp import TPTrainer
 
         batches = synth_batches(hooks, N, d, 2, act_dtype, device, seed=rank * 7919)
-        trainer = TPTrainer(cfg, batches, device=device, num_batches=10_000)
+        sim = SimComm(args.simulate_tp, M // args.simulate_tp) if args.simulate_tp > 1 and world == 1 else None
+        trainer = TPTrainer(cfg, batches, device=device, num_batches=10_000, comm=sim)
         parallelism = f"tp{world}" if world > 1 else "single"
+        if sim is not None:
+            world, parallelism = args.simulate_tp, f"SIMULATED rank 0 of tp{args.simulate_tp}, no RCCL"
     else:
         batches = synth_batches(hooks, N, d, 2, act_dtype, device)
         trainer = Trainer(cfg, batches, device=device, num_batches=10_000)
@@ -135,8 +167,10 @@ def main():
     fused = getattr(getattr(trainer, "engine", None), "fused_opt", None) is not None
     P_adam = sum(p.numel() for sae in trainer.saes.values() for p in sae.parameters() if not (fused and p.dim() == 2 and p.shape[0] > d))
 
+    real_world = int(os.environ.get("WORLD_SIZE", "1"))
+
     def barrier():
-        if world > 1:
+        if real_world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -152,7 +186,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     hip_ops.PROFILE = None
-    if world > 1:
+    if real_world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -197,7 +231,7 @@ def main():
             cpu = cpu_baseline.run(L=2, d=d, M=M, k=k, N=1024, min_seconds=args.cpu_seconds, full_L=L)
         line = {
             "metric": "train tokens/sec, GPT-2 CLT (exp128,k32) fwd+bwd+Adam", "value": round(value, 1),
-            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "tokens/s", "n_gpus": real_world, "simulated": args.simulate_tp > 1 and real_world == 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "host_issue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
@@ -209,7 +243,7 @@ def main():
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if real_world > 1:
         torch.distributed.destroy_process_group()
 
 

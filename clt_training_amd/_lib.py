@@ -24,6 +24,16 @@ class AdamTensor(C.Structure):
                 ("p_dtype", C.c_int32), ("g_dtype", C.c_int32), ("pad_", C.c_int32)]
 
 
+class DecodeSource(C.Structure):
+    """clt_decode_source (include/clt_mi355.h)."""
+
+    _fields_ = [("idx", _vp), ("v", _vp), ("post_enc", _vp), ("post_scale", _vp), ("W", _vp), ("acts_out", _vp),
+                ("grad_acts", _vp), ("e_post", _vp), ("e_scale", _vp), ("lat_begin", _i64), ("weight", _f32),
+                ("accumulate_grad_acts", C.c_int32)]
+
+
+CLT_DECODE_MAX_SOURCES = 16
+
 # name -> (restype, argtypes); kept in the order of include/clt_mi355.h
 SIGNATURES = {
     "clt_version": (_i32, []),
@@ -36,6 +46,8 @@ SIGNATURES = {
                               _vp]),
     "clt_decode_bwd_acts": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp,
                                    _i64, _i32, _vp]),
+    "clt_decode_fwd_multi": (_i32, [_vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "clt_decode_bwd_acts_multi": (_i32, [_vp, _i32, _i32, _i32, _i64, _i32, _vp, _i32, _i64, _i32, _vp]),
     "clt_segments_workspace_bytes": (_sz, [_i64, _i64]),
     "clt_segments_build": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "clt_spt_dense": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),

@@ -400,3 +400,359 @@ extern "C" int clt_decode_bwd_acts(const int64_t* idx, const void* v, int v_dtyp
   CLT_CHECK_LAUNCH("clt_decode_bwd_acts");
   return CLT_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Multi-source variants (CLT fan-out, runner.py:43-71): the entries of all live sources of one target form ONE list
+// per token: entry e = s * k + j.  Each lane resolves its entry's source through a copy of the descriptor table in
+// LDS, turns it into (row address, weight), entries of other shards are compacted away, and the gather loop no
+// longer knows about sources: U rows in flight whatever k / tp is.
+namespace clt {
+
+struct SrcTable {
+  clt_decode_source s[CLT_DECODE_MAX_SOURCES];
+};
+
+__device__ __forceinline__ void stage_table(const SrcTable& tab, int ns, clt_decode_source* lt) {
+  // static indices only: the descriptors are read straight from the kernel-argument segment (scalar loads)
+#pragma unroll
+  for (int i = 0; i < CLT_DECODE_MAX_SOURCES; ++i)
+    if (i < ns && threadIdx.x == i) lt[i] = tab.s[i];
+  __syncthreads();
+}
+
+template <typename WT, typename OT, int CH, int U>
+__global__ __launch_bounds__(256) void decode_fwd_multi_kernel(const SrcTable tab, int ns, int v_dtype, int64_t M, int d,
+                                                               const float* __restrict__ bias, OT* out, int flags,
+                                                               int64_t N, int k) {
+  constexpr int E = Chunk<WT>::E;
+  __shared__ clt_decode_source lt[CLT_DECODE_MAX_SOURCES];
+  stage_table(tab, ns, lt);
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;  // wave-uniform, after the only barrier
+  const int nchunks = d / E;
+  const size_t row_bytes = (size_t)d * sizeof(WT);
+  float acc[CH][E];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+
+  const int total = ns * k;
+  for (int e0 = 0; e0 < total; e0 += 64) {
+    const int e = e0 + lane;
+    const bool active = e < total;
+    bool valid = false;
+    float my_a = 0.f;
+    unsigned my_lo = 0, my_hi = 0;
+    if (active) {
+      const int s = e / k, j = e - s * k;
+      const clt_decode_source& S = lt[s];
+      const int64_t o = n * k + j;
+      const int64_t rr = S.idx[o] - S.lat_begin;
+      valid = rr >= 0 && rr < M;
+      float a = 0.f;
+      if (valid) {
+        const float vv = load_scalar(S.v, v_dtype, o);
+        a = post_affine(vv, (int)rr, S.post_enc, S.post_scale);
+        if (flags & CLT_DECODE_ROUND_ACTS) a = bf16_bits_to_f32(f32_to_bf16_bits(a));
+        const uint64_t addr = reinterpret_cast<uint64_t>(S.W) + (uint64_t)rr * row_bytes;
+        my_lo = (unsigned)addr;
+        my_hi = (unsigned)(addr >> 32);
+      }
+      if (S.acts_out) S.acts_out[o] = a;
+      my_a = a * S.weight;
+    }
+    int cnt = min(64, total - e0);
+    if (__ballot(valid) != __ballot(active)) {
+      int nv;
+      const int dest = compact_dest(valid, active, nv);
+      my_lo = (unsigned)permute_push_i(dest, (int)my_lo);
+      my_hi = (unsigned)permute_push_i(dest, (int)my_hi);
+      my_a = permute_push_f(dest, my_a);
+      cnt = nv;
+    }
+    for (int jj = 0; jj < cnt; jj += U) {
+      uint4 raw[U][CH];
+      float a_u[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jl = min(jj + u, cnt - 1);
+        const uint64_t addr = ((uint64_t)(unsigned)readlane_i((int)my_hi, jl) << 32) | (unsigned)readlane_i((int)my_lo, jl);
+        a_u[u] = (jj + u < cnt) ? readlane_f(my_a, jl) : 0.f;
+        const char* row = reinterpret_cast<const char*>(addr);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            float w[E];
+            Chunk<WT>::expand(raw[u][c], w);
+#pragma unroll
+            for (int q = 0; q < E; ++q) acc[c][q] = fmaf(a_u[u], w[q], acc[c][q]);
+          }
+        }
+      }
+    }
+  }
+
+  OT* orow = out + n * (int64_t)d;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      if (bias) {
+        float b[E];
+        load_elems<float, E>(bias + ch * E, b);
+#pragma unroll
+        for (int q = 0; q < E; ++q) acc[c][q] += b[q];
+      }
+      if (flags & CLT_DECODE_ACCUMULATE) {
+        float o[E];
+        load_elems<OT, E>(orow + ch * E, o);
+#pragma unroll
+        for (int q = 0; q < E; ++q) acc[c][q] += o[q];
+      }
+      store_elems<OT, E>(orow + ch * E, acc[c]);
+    }
+  }
+}
+
+template <typename WT, typename GT, int CH, int U>
+__global__ __launch_bounds__(256) void decode_bwd_acts_multi_kernel(const SrcTable tab, int ns, int v_dtype, int64_t M,
+                                                                    int d, const GT* __restrict__ G, int64_t N, int k) {
+  constexpr int E = Chunk<WT>::E;
+  __shared__ clt_decode_source lt[CLT_DECODE_MAX_SOURCES];
+  stage_table(tab, ns, lt);
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int nchunks = d / E;
+  const size_t row_bytes = (size_t)d * sizeof(WT);
+  float g[CH][E];
+  const GT* grow = G + n * (int64_t)d;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      load_elems<GT, E>(grow + ch * E, g[c]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < E; ++q) g[c][q] = 0.f;
+    }
+  }
+
+  const int total = ns * k;
+  for (int e0 = 0; e0 < total; e0 += 64) {
+    const int e = e0 + lane;
+    const bool active = e < total;
+    bool valid = false;
+    int my_r = 0;
+    unsigned my_lo = 0, my_hi = 0;
+    if (active) {
+      const int s = e / k, j = e - s * k;
+      const clt_decode_source& S = lt[s];
+      const int64_t rr = S.idx[n * k + j] - S.lat_begin;
+      valid = rr >= 0 && rr < M;
+      if (valid) {
+        my_r = (int)rr;
+        const uint64_t addr = reinterpret_cast<uint64_t>(S.W) + (uint64_t)rr * row_bytes;
+        my_lo = (unsigned)addr;
+        my_hi = (unsigned)(addr >> 32);
+      }
+    }
+    int my_e = e;  // the entry this lane reports on (changes under compaction)
+    int cnt = min(64, total - e0);
+    if (__ballot(valid) != __ballot(active)) {
+      int nv;
+      const int dest = compact_dest(valid, active, nv);
+      my_lo = (unsigned)permute_push_i(dest, (int)my_lo);
+      my_hi = (unsigned)permute_push_i(dest, (int)my_hi);
+      my_r = permute_push_i(dest, my_r);
+      my_e = permute_push_i(dest, e);
+      valid = lane < nv;
+      cnt = nv;
+    }
+    float my_ga = 0.f;
+    for (int jj = 0; jj < cnt; jj += U) {
+      uint4 raw[U][CH];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jl = min(jj + u, cnt - 1);
+        const uint64_t addr = ((uint64_t)(unsigned)readlane_i((int)my_hi, jl) << 32) | (unsigned)readlane_i((int)my_lo, jl);
+        const char* row = reinterpret_cast<const char*>(addr);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            float w[E];
+            Chunk<WT>::expand(raw[u][c], w);
+#pragma unroll
+            for (int q = 0; q < E; ++q) part = fmaf(g[c][q], w[q], part);
+          }
+        }
+        part = wave_sum(part);
+        if (jj + u < cnt && lane == jj + u) my_ga = part;
+      }
+    }
+    if (my_e < total) {  // every entry of the chunk is reported by exactly one lane
+      const int s = my_e / k, j = my_e - s * k;
+      const clt_decode_source& S = lt[s];
+      const int64_t o = n * k + j;
+      float u_ = 0.f, es = 0.f, ep = 0.f;
+      if (valid) {
+        const float ga = my_ga * S.weight;
+        const float vv = load_scalar(S.v, v_dtype, o);
+        const float pos = vv > 0.f ? 1.f : 0.f;
+        u_ = S.post_scale ? ga * S.post_scale[my_r] : ga;
+        es = ga * (vv + (S.post_enc ? S.post_enc[my_r] * pos : 0.f));
+        ep = u_ * pos;
+      }
+      if (S.e_scale) S.e_scale[o] = es;
+      if (S.e_post) S.e_post[o] = ep;
+      if (S.accumulate_grad_acts) {
+        if (valid) S.grad_acts[o] += u_;
+      } else {
+        S.grad_acts[o] = u_;
+      }
+    }
+  }
+}
+
+static int check_sources(const char* name, const clt_decode_source* hs, int ns, bool bwd) {
+  CLT_CHECK_ARG(hs && ns >= 1, "%s: no sources", name);
+  CLT_UNSUPPORTED(ns <= CLT_DECODE_MAX_SOURCES, "%s: %d sources > CLT_DECODE_MAX_SOURCES", name, ns);
+  for (int i = 0; i < ns; ++i) {
+    CLT_CHECK_ARG(hs[i].idx && hs[i].v && hs[i].W && aligned16(hs[i].W), "%s: source %d: null or misaligned pointer", name, i);
+    if (bwd) {
+      CLT_CHECK_ARG(hs[i].grad_acts, "%s: source %d: grad_acts is null", name, i);
+      CLT_CHECK_ARG(!hs[i].e_scale || hs[i].post_scale, "%s: source %d: e_scale requires post_scale", name, i);
+    }
+  }
+  return CLT_OK;
+}
+
+}  // namespace clt
+
+template <typename WT, typename OT>
+static int launch_decode_fwd_multi(int ch, dim3 grid, hipStream_t st, const SrcTable& tab, int ns, int v_dtype, int64_t M,
+                                   int d, const float* bias, void* out, int flags, int64_t N, int k) {
+#define LAUNCH(CH, U)                                                                                                \
+  hipLaunchKernelGGL((decode_fwd_multi_kernel<WT, OT, CH, U>), grid, dim3(256), 0, st, tab, ns, v_dtype, M, d, bias, \
+                     (OT*)out, flags, N, k)
+  switch (ch) {
+    case 1: LAUNCH(1, 8); break;
+    case 2: LAUNCH(2, 8); break;
+    case 4: LAUNCH(4, 4); break;
+    case 8: LAUNCH(8, 2); break;
+    case 16: LAUNCH(16, 1); break;
+    default: return CLT_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH
+  return CLT_OK;
+}
+
+extern "C" int clt_decode_fwd_multi(const clt_decode_source* h_sources, int n_sources, int v_dtype, int w_dtype,
+                                    int64_t M, int d, const float* bias, void* out, int out_dtype, int flags, int64_t N,
+                                    int k, clt_stream_t stream) {
+  int rc = check_sources("clt_decode_fwd_multi", h_sources, n_sources, false);
+  if (rc != CLT_OK) return rc;
+  CLT_CHECK_ARG(out, "clt_decode_fwd_multi: null pointer");
+  CLT_CHECK_ARG(N >= 0 && k > 0 && d > 0 && M > 0 && M < (1ll << 31) && (int64_t)n_sources * k < (1ll << 30),
+                "clt_decode_fwd_multi: bad sizes N=%lld k=%d d=%d M=%lld", (long long)N, k, d, (long long)M);
+  CLT_CHECK_ARG(valid_dtype(v_dtype) && valid_dtype(w_dtype) && valid_dtype(out_dtype), "clt_decode_fwd_multi: bad dtype");
+  CLT_CHECK_ARG(aligned16(out) && (!bias || aligned16(bias)), "clt_decode_fwd_multi: pointers must be 16-byte aligned");
+  const int E = w_dtype == CLT_BF16 ? 8 : 4;
+  CLT_UNSUPPORTED(d % 8 == 0 || (d % 4 == 0 && w_dtype == CLT_F32 && out_dtype == CLT_F32),
+                  "clt_decode_fwd_multi: d=%d must be a multiple of 8 (or 4 for all-fp32)", d);
+  const int ch = pick_ch(d, E);
+  CLT_UNSUPPORTED(ch > 0, "clt_decode_fwd_multi: d=%d too wide", d);
+  if (N == 0) return CLT_OK;
+  SrcTable tab = {};
+  for (int i = 0; i < n_sources; ++i) tab.s[i] = h_sources[i];
+  dim3 grid((unsigned)((N + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (w_dtype == CLT_BF16 && out_dtype == CLT_BF16)
+    rc = launch_decode_fwd_multi<bf16_t, bf16_t>(ch, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
+  else if (w_dtype == CLT_BF16 && out_dtype == CLT_F32)
+    rc = launch_decode_fwd_multi<bf16_t, float>(ch, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
+  else if (w_dtype == CLT_F32 && out_dtype == CLT_F32)
+    rc = launch_decode_fwd_multi<float, float>(ch, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
+  else
+    rc = launch_decode_fwd_multi<float, bf16_t>(ch, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
+  if (rc != CLT_OK) {
+    set_error("clt_decode_fwd_multi: unsupported width d=%d", d);
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_decode_fwd_multi");
+  return CLT_OK;
+}
+
+template <typename WT, typename GT>
+static int launch_decode_bwd_multi(int ch, dim3 grid, hipStream_t st, const SrcTable& tab, int ns, int v_dtype, int64_t M,
+                                   int d, const void* G, int64_t N, int k) {
+#define LAUNCH(CH, U)                                                                                               \
+  hipLaunchKernelGGL((decode_bwd_acts_multi_kernel<WT, GT, CH, U>), grid, dim3(256), 0, st, tab, ns, v_dtype, M, d, \
+                     (const GT*)G, N, k)
+  switch (ch) {
+    case 1: LAUNCH(1, 8); break;
+    case 2: LAUNCH(2, 8); break;
+    case 4: LAUNCH(4, 4); break;
+    case 8: LAUNCH(8, 2); break;
+    case 16: LAUNCH(16, 1); break;
+    default: return CLT_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH
+  return CLT_OK;
+}
+
+extern "C" int clt_decode_bwd_acts_multi(const clt_decode_source* h_sources, int n_sources, int v_dtype, int w_dtype,
+                                         int64_t M, int d, const void* G, int g_dtype, int64_t N, int k,
+                                         clt_stream_t stream) {
+  int rc = check_sources("clt_decode_bwd_acts_multi", h_sources, n_sources, true);
+  if (rc != CLT_OK) return rc;
+  CLT_CHECK_ARG(G && aligned16(G), "clt_decode_bwd_acts_multi: G is null or misaligned");
+  CLT_CHECK_ARG(N >= 0 && k > 0 && d > 0 && M > 0 && M < (1ll << 31) && (int64_t)n_sources * k < (1ll << 30),
+                "clt_decode_bwd_acts_multi: bad sizes");
+  CLT_CHECK_ARG(valid_dtype(v_dtype) && valid_dtype(w_dtype) && valid_dtype(g_dtype), "clt_decode_bwd_acts_multi: bad dtype");
+  const int E = w_dtype == CLT_BF16 ? 8 : 4;
+  CLT_UNSUPPORTED(d % 8 == 0 || (d % 4 == 0 && w_dtype == CLT_F32 && g_dtype == CLT_F32),
+                  "clt_decode_bwd_acts_multi: d=%d must be a multiple of 8 (or 4 for all-fp32)", d);
+  const int ch = pick_ch(d, E);
+  CLT_UNSUPPORTED(ch > 0, "clt_decode_bwd_acts_multi: d=%d too wide", d);
+  if (N == 0) return CLT_OK;
+  SrcTable tab = {};
+  for (int i = 0; i < n_sources; ++i) tab.s[i] = h_sources[i];
+  dim3 grid((unsigned)((N + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (w_dtype == CLT_BF16 && g_dtype == CLT_BF16)
+    rc = launch_decode_bwd_multi<bf16_t, bf16_t>(ch, grid, st, tab, n_sources, v_dtype, M, d, G, N, k);
+  else if (w_dtype == CLT_BF16 && g_dtype == CLT_F32)
+    rc = launch_decode_bwd_multi<bf16_t, float>(ch, grid, st, tab, n_sources, v_dtype, M, d, G, N, k);
+  else if (w_dtype == CLT_F32 && g_dtype == CLT_F32)
+    rc = launch_decode_bwd_multi<float, float>(ch, grid, st, tab, n_sources, v_dtype, M, d, G, N, k);
+  else
+    rc = launch_decode_bwd_multi<float, bf16_t>(ch, grid, st, tab, n_sources, v_dtype, M, d, G, N, k);
+  if (rc != CLT_OK) {
+    set_error("clt_decode_bwd_acts_multi: unsupported width d=%d", d);
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_decode_bwd_acts_multi");
+  return CLT_OK;
+}

@@ -62,7 +62,10 @@ __device__ __forceinline__ void store_row_chunk(OT* p, const float (&a)[E]) {
 // dependent chain offsets -> perm -> dense row is paid once per RW rows instead of once per row; the gathers of
 // consecutive output rows then issue back to back (most rows hold 0-8 entries).  Rows are finished in order:
 // when the owning row of the next entry changes, the accumulator is stored (zeros for empty rows) and cleared.
-constexpr int RW = 8;
+// RW = 8 when there are rows to spare (M / 8 waves still fill the chip); fewer rows per wave when the table is
+// short and its rows long (a latent shard of a large token batch: M / tp rows, N * k / M * tp entries each).
+// The summation order within a row does not depend on RW: results are bitwise the same.
+static int pick_rw(int64_t M) { return M >= 8 * 8192 ? 8 : M >= 4 * 8192 ? 4 : M >= 2 * 8192 ? 2 : 1; }
 
 // Optimizer state of the rows for the fused variant (clt_spt_dense_adam): the finished gradient row never goes
 // to memory; it is rounded to the parameter dtype (as the .grad tensor would be) and consumed on the spot by
@@ -89,7 +92,7 @@ __device__ __forceinline__ void load_row_chunk(const PT* p, float (&a)[E]) {
   }
 }
 
-template <typename DT, typename OT, int CH, int U, bool ADAM>
+template <typename DT, typename OT, int CH, int U, bool ADAM, int RW>
 __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ offsets, int64_t M,
                                                         const float* __restrict__ vals,
@@ -321,17 +324,26 @@ extern "C" int clt_segments_build(const int64_t* idx, int64_t n, int64_t M, int6
 }
 
 template <typename DT, typename OT, bool ADAM = false>
-static int launch_spt(int ch, dim3 grid, hipStream_t st, const int32_t* perm, const int32_t* offsets, int64_t M,
+static int launch_spt(int ch, hipStream_t st, const int32_t* perm, const int32_t* offsets, int64_t M,
                       const float* vals, const void* gate, int gate_dtype, const void* dense, int d, int k, void* out,
                       float* rowsum, AdamRows ad = AdamRows()) {
-#define LAUNCH(CH, U)                                                                                                \
-  hipLaunchKernelGGL((spt_dense_kernel<DT, OT, CH, U, ADAM>), grid, dim3(256), 0, st, perm, offsets, M, vals, gate,  \
-                     gate_dtype, (const DT*)dense, d, k, (OT*)out, rowsum, ad)
+  const int rw = pick_rw(M);
+  const dim3 grid((unsigned)((M + 4 * rw - 1) / (4 * rw)));
+#define LAUNCH_RW(CH, U, RW_)                                                                                         \
+  hipLaunchKernelGGL((spt_dense_kernel<DT, OT, CH, U, ADAM, RW_>), grid, dim3(256), 0, st, perm, offsets, M, vals,    \
+                     gate, gate_dtype, (const DT*)dense, d, k, (OT*)out, rowsum, ad)
+#define LAUNCH(CH, U)                    \
+  do {                                   \
+    if (rw == 8) LAUNCH_RW(CH, U, 8);    \
+    else if (rw == 4) LAUNCH_RW(CH, U, 4); \
+    else if (rw == 2) LAUNCH_RW(CH, U, 2); \
+    else LAUNCH_RW(CH, U, 1);            \
+  } while (0)
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
     case 2:
-      if (ADAM) LAUNCH(2, 4);  // fewer gathers in flight, more waves: the state streams need the occupancy
-      else LAUNCH(2, 8);
+      if (ADAM) { LAUNCH(2, 4); }  // fewer gathers in flight, more waves: the state streams need the occupancy
+      else { LAUNCH(2, 8); }
       break;
     case 4: LAUNCH(4, 4); break;
     case 8: LAUNCH(8, 2); break;
@@ -339,6 +351,7 @@ static int launch_spt(int ch, dim3 grid, hipStream_t st, const int32_t* perm, co
     default: return CLT_ERR_UNSUPPORTED;
   }
 #undef LAUNCH
+#undef LAUNCH_RW
   return CLT_OK;
 }
 
@@ -356,17 +369,16 @@ extern "C" int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_
   int chunks = d / E, ch = (chunks + 63) / 64;
   ch = ch <= 1 ? 1 : ch <= 2 ? 2 : ch <= 4 ? 4 : ch <= 8 ? 8 : ch <= 16 ? 16 : -1;
   CLT_UNSUPPORTED(ch > 0, "clt_spt_dense: d=%d too wide", d);
-  dim3 grid((unsigned)((M + 4 * RW - 1) / (4 * RW)));
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (dense_dtype == CLT_BF16 && out_dtype == CLT_BF16)
-    rc = launch_spt<bf16_t, bf16_t>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
+    rc = launch_spt<bf16_t, bf16_t>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
   else if (dense_dtype == CLT_BF16 && out_dtype == CLT_F32)
-    rc = launch_spt<bf16_t, float>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
+    rc = launch_spt<bf16_t, float>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
   else if (dense_dtype == CLT_F32 && out_dtype == CLT_F32)
-    rc = launch_spt<float, float>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
+    rc = launch_spt<float, float>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
   else
-    rc = launch_spt<float, bf16_t>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
+    rc = launch_spt<float, bf16_t>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
   if (rc != CLT_OK) {
     set_error("clt_spt_dense: unsupported width");
     return rc;
@@ -401,17 +413,16 @@ extern "C" int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, i
   ad.b2 = b2;
   ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   ad.eps = eps;
-  dim3 grid((unsigned)((M + 4 * RW - 1) / (4 * RW)));
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (dense_dtype == CLT_BF16 && p_dtype == CLT_BF16)
-    rc = launch_spt<bf16_t, bf16_t, true>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
+    rc = launch_spt<bf16_t, bf16_t, true>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
   else if (dense_dtype == CLT_BF16 && p_dtype == CLT_F32)
-    rc = launch_spt<bf16_t, float, true>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
+    rc = launch_spt<bf16_t, float, true>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
   else if (dense_dtype == CLT_F32 && p_dtype == CLT_F32)
-    rc = launch_spt<float, float, true>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
+    rc = launch_spt<float, float, true>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
   else
-    rc = launch_spt<float, bf16_t, true>(ch, grid, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
+    rc = launch_spt<float, bf16_t, true>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
   if (rc != CLT_OK) {
     set_error("clt_spt_dense_adam: unsupported width");
     return rc;

@@ -295,23 +295,37 @@ class CLTEngine:
         # The skip connections and decoder biases of all live sources (sparse_coder.py:186-190, summed by
         # runner.py:46-49) are ONE GEMM: the live layers' inputs sit side by side in a persistent [N, L*d] buffer,
         # so sum_i x_i @ W_skip_i^T = X_live @ cat_i(W_skip_i^T), with 1/div folded into the other sources' blocks.
-        P_cur = P_oth = None
-        for st in self.live:
-            li = self.coders[st.layer]
-            t = st.slot
-            ps = li.post_enc_scales[t] if li.post_enc_scales is not None else None
-            is_cur = st is me
-            acc_into = None if is_cur else P_oth
-            out, acts = ops.decode_fwd(st.idx, st.v, li.W_decs[t], post_enc=li.post_encs[t], post_scale=ps,
-                                       round_acts=li.W_decs[t].dtype == torch.bfloat16, want_acts=True,
-                                       lat_begin=li.lat_begin, out=acc_into, accumulate=acc_into is not None)
-            st.acts[t] = acts
-            if is_cur:
-                P_cur = out
-            else:
-                P_oth = out
-        P = P_cur if P_oth is None else (P_cur + P_oth if div == 1 else P_cur + P_oth / div)
         scale = [1.0 if st is me else 1.0 / div for st in self.live]
+        Wt = [self.coders[st.layer].W_decs[st.slot] for st in self.live]
+        multi = hasattr(ops, "decode_fwd_multi") and all(w.shape == Wt[0].shape and w.dtype == Wt[0].dtype for w in Wt)
+        if multi:  # every live source in ONE launch: fp32 sum over all sources, one rounding, one output write
+            srcs = []
+            for st, sc_ in zip(self.live, scale):
+                li = self.coders[st.layer]
+                t = st.slot
+                srcs.append(dict(idx=st.idx, v=st.v, W=li.W_decs[t], post_enc=li.post_encs[t],
+                                 post_scale=li.post_enc_scales[t] if li.post_enc_scales is not None else None,
+                                 lat_begin=li.lat_begin, weight=sc_))
+            P, acts_l = ops.decode_fwd_multi(srcs, round_acts=Wt[0].dtype == torch.bfloat16, want_acts=True)
+            for st, a in zip(self.live, acts_l):
+                st.acts[st.slot] = a
+        else:
+            P_cur = P_oth = None
+            for st in self.live:
+                li = self.coders[st.layer]
+                t = st.slot
+                ps = li.post_enc_scales[t] if li.post_enc_scales is not None else None
+                is_cur = st is me
+                acc_into = None if is_cur else P_oth
+                out, acts = ops.decode_fwd(st.idx, st.v, li.W_decs[t], post_enc=li.post_encs[t], post_scale=ps,
+                                           round_acts=li.W_decs[t].dtype == torch.bfloat16, want_acts=True,
+                                           lat_begin=li.lat_begin, out=acc_into, accumulate=acc_into is not None)
+                st.acts[t] = acts
+                if is_cur:
+                    P_cur = out
+                else:
+                    P_oth = out
+            P = P_cur if P_oth is None else (P_cur + P_oth if div == 1 else P_cur + P_oth / div)
         bs = torch.stack([self.coders[st.layer].b_decs[st.slot].float() for st in self.live])  # [n_live, d]
         if div != 1:
             bs = bs * torch.tensor(scale, dtype=torch.float32, device=bs.device).unsqueeze(1)
@@ -346,6 +360,17 @@ class CLTEngine:
         G_r_div = G_r if div == 1 else (G_r.float() / div).to(cd)
         gb = G_r.sum(0, dtype=torch.float32)  # d b_dec: the same column sums for every live source (x 1/div)
         gWs = (G_r.mT @ X_live) if X_live is not None else None  # [d, n_live*d]: block i is d W_skip of source i
+        bwd_multi = None
+        if multi and hasattr(ops, "decode_bwd_acts_multi"):  # grad wrt the activations of every live source: ONE launch
+            srcs = []
+            for st, sc_ in zip(self.live, scale):
+                li = self.coders[st.layer]
+                t = st.slot
+                srcs.append(dict(idx=st.idx, v=st.v, W=li.W_decs[t], post_enc=li.post_encs[t],
+                                 post_scale=li.post_enc_scales[t] if li.post_enc_scales is not None else None,
+                                 lat_begin=li.lat_begin, weight=sc_, grad_acts=st.gv,
+                                 want_e_post=li.post_encs[t].requires_grad))
+            bwd_multi = ops.decode_bwd_acts_multi(srcs, G)
         for n_st, st in enumerate(self.live):
             li = self.coders[st.layer]
             t = st.slot
@@ -360,9 +385,12 @@ class CLTEngine:
                     self._acc_grad(li.W_skips[t], (Gi_r.mT @ st.xn_r).float())
             ps = li.post_enc_scales[t] if li.post_enc_scales is not None else None
             need_pe = li.post_encs[t].requires_grad
-            _, e_post, e_scale = ops.decode_bwd_acts(st.idx, st.v, li.W_decs[t], Gi, post_enc=li.post_encs[t],
-                                                     post_scale=ps, grad_acts=st.gv, want_e_post=need_pe,
-                                                     lat_begin=li.lat_begin)
+            if bwd_multi is not None:
+                _, e_post, e_scale = bwd_multi[n_st]
+            else:
+                _, e_post, e_scale = ops.decode_bwd_acts(st.idx, st.v, li.W_decs[t], Gi, post_enc=li.post_encs[t],
+                                                         post_scale=ps, grad_acts=st.gv, want_e_post=need_pe,
+                                                         lat_begin=li.lat_begin)
             if st.seg is None:
                 st.seg = ops.segments_build(st.idx, li.m_local, lat_begin=li.lat_begin)
             self._grad_rows(li.W_decs[t], st.seg, st.acts.pop(t).view(-1), Gi, acc_steps)

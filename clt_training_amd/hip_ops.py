@@ -181,6 +181,85 @@ def decode_bwd_acts(idx: Tensor, v: Tensor, W: Tensor, G: Tensor, *, post_enc: O
     return grad_acts, e_post, e_scale
 
 
+def _source_table(sources, fields):
+    tab = (_lib.DecodeSource * len(sources))()
+    keep = []  # the contiguous copies must outlive the launch call
+    for ent, src in zip(tab, sources):
+        for name in fields:
+            t = src.get(name)
+            if t is not None:
+                t = _idx(t) if name == "idx" else _c(t)
+                keep.append(t)
+                setattr(ent, name, t.data_ptr())
+        ent.lat_begin = int(src.get("lat_begin", 0))
+        ent.weight = float(src.get("weight", 1.0))
+    return tab, keep
+
+
+def decode_fwd_multi(sources, *, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, out_dtype=None,
+                     accumulate: bool = False, round_acts: bool = False, want_acts: bool = False):
+    """One launch for all live sources of a target (clt_decode_fwd_multi).  ``sources``: dicts with idx, v, W and
+    optionally post_enc, post_scale, lat_begin, weight.  Returns out (and the list of a' per source)."""
+    assert 1 <= len(sources)
+    W0, i0, v0 = sources[0]["W"], sources[0]["idx"], sources[0]["v"]
+    N, k = i0.shape
+    M, d = W0.shape
+    for s_ in sources:
+        assert s_["W"].shape == (M, d) and s_["W"].dtype == W0.dtype and s_["idx"].shape == (N, k) and s_["v"].dtype == v0.dtype
+        for nm in ("post_enc", "post_scale"):
+            t = s_.get(nm)
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    out_dtype = out_dtype or W0.dtype
+    if out is None:
+        assert not accumulate
+        out = torch.empty(N, d, dtype=out_dtype, device=W0.device)
+    acts = None
+    if want_acts:
+        acts = [torch.empty(N, k, dtype=torch.float32, device=W0.device) for _ in sources]
+        sources = [dict(s_, acts_out=a) for s_, a in zip(sources, acts)]
+    flags = (CLT_DECODE_ACCUMULATE if accumulate else 0) | (CLT_DECODE_ROUND_ACTS if round_acts else 0)
+    step = _lib.CLT_DECODE_MAX_SOURCES
+    for c0 in range(0, len(sources), step):  # more live sources than one launch takes: accumulate group by group
+        tab, keep = _source_table(sources[c0:c0 + step], ("idx", "v", "post_enc", "post_scale", "W", "acts_out"))
+        _call("clt_decode_fwd_multi", C.cast(tab, C.c_void_p), len(tab), _dt(v0), _dt(W0), M, d,
+              _ptr(bias) if c0 == 0 else None, _ptr(out), _dt(out), flags | (CLT_DECODE_ACCUMULATE if c0 else 0), N, k,
+              _stream(W0))
+        del keep
+    return (out, acts) if want_acts else out
+
+
+def decode_bwd_acts_multi(sources, G: Tensor):
+    """One launch for all live sources of a target (clt_decode_bwd_acts_multi).  ``sources``: dicts with idx, v, W,
+    optionally post_enc, post_scale, lat_begin, weight (factor on G), grad_acts (accumulated into when given),
+    want_e_post.  Returns a list of (grad_acts, e_post, e_scale) per source."""
+    G = _c(G)
+    W0, i0, v0 = sources[0]["W"], sources[0]["idx"], sources[0]["v"]
+    N, k = i0.shape
+    M, d = W0.shape
+    outs, full = [], []
+    for s_ in sources:
+        assert s_["W"].shape == (M, d) and s_["W"].dtype == W0.dtype and s_["idx"].shape == (N, k) and s_["v"].dtype == v0.dtype
+        ga = s_.get("grad_acts")
+        acc = ga is not None
+        if ga is None:
+            ga = torch.empty(N, k, dtype=torch.float32, device=W0.device)
+        assert ga.dtype == torch.float32 and ga.is_contiguous()
+        e_post = torch.empty(N, k, dtype=torch.float32, device=W0.device) if s_.get("want_e_post") else None
+        e_scale = torch.empty(N, k, dtype=torch.float32, device=W0.device) if s_.get("post_scale") is not None else None
+        outs.append((ga, e_post, e_scale))
+        full.append(dict(s_, grad_acts=ga, e_post=e_post, e_scale=e_scale, _acc=acc))
+    step = _lib.CLT_DECODE_MAX_SOURCES
+    for c0 in range(0, len(full), step):
+        grp = full[c0:c0 + step]
+        tab, keep = _source_table(grp, ("idx", "v", "post_enc", "post_scale", "W", "grad_acts", "e_post", "e_scale"))
+        for ent, s_ in zip(tab, grp):
+            ent.accumulate_grad_acts = int(s_["_acc"])
+        _call("clt_decode_bwd_acts_multi", C.cast(tab, C.c_void_p), len(tab), _dt(v0), _dt(W0), M, d, _ptr(G), _dt(G),
+              N, k, _stream(W0))
+        del keep
+    return outs
+
+
 # ----------------------------------------------------------------------------- segments
 class Segments:
     """Entries (token, slot) grouped by latent: built once per source layer, shared by

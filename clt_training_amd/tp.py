@@ -22,14 +22,14 @@ from .trainer import WarmupLinearSchedule
 class TPTrainer:
     def __init__(self, cfg: TrainConfig, dataset, model=None, mesh=None, *, device="cuda",
                  input_widths: Optional[dict] = None, num_batches: Optional[int] = None, ops=None, group=None,
-                 optimizer_cls=None, coders: Optional[list] = None):
+                 optimizer_cls=None, coders: Optional[list] = None, comm: Optional[Comm] = None):
         assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
         if cfg.optimizer != "adam" or cfg.loss_fn != "fvu":
             raise NotImplementedError("only optimizer='adam', loss_fn='fvu' are on the MI355X hot path")
         cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
         self.cfg, self.dataset = cfg, dataset
         self.device = torch.device(device)
-        self.comm = Comm(group)
+        self.comm = comm or Comm(group)
         if ops is None:
             from . import hip_ops as ops  # the product path: HIP kernels, no CPU fallback
         self.ops = ops
@@ -70,7 +70,9 @@ class TPTrainer:
         self.global_step = 0
         self.num_tokens_since_fired = {h: torch.zeros(s.m_local, device=self.device, dtype=torch.long)
                                        for h, s in self.saes.items()}
-        self.did_fire = {h: torch.zeros(s.m_local, device=self.device, dtype=torch.bool) for h, s in self.saes.items()}
+        # one spare slot at the end takes the indices owned by other ranks (no boolean-mask indexing: no host sync)
+        self._did_fire = {h: torch.zeros(s.m_local + 1, device=self.device, dtype=torch.bool) for h, s in self.saes.items()}
+        self.did_fire = {h: f[:-1] for h, f in self._did_fire.items()}
         self.num_tokens_in_step = 0
         self.last_fvu = {}
 
@@ -93,8 +95,9 @@ class TPTrainer:
             self.last_fvu[name] = eng.layer_step(j, x, y, mask, acc_steps)
             # fired-latent bookkeeping on this rank's latent range (trainer.py:622-628)
             loc = eng.last_idx[j].flatten() - sae.lat_begin
-            loc = loc[(loc >= 0) & (loc < sae.m_local)] if self.comm.world > 1 else loc
-            self.did_fire[name].index_fill_(0, loc, True)
+            if self.comm.world > 1:
+                loc = torch.where((loc >= 0) & (loc < sae.m_local), loc, sae.m_local)
+            self._did_fire[name].index_fill_(0, loc, True)
         self.num_tokens_in_step += n_tok
         step, substep = divmod(self.global_step + 1, cfg.grad_acc_steps)
         if substep == 0:
@@ -113,7 +116,7 @@ class TPTrainer:
                     counts += self.num_tokens_in_step
                     counts.masked_fill_(self.did_fire[name], 0)  # no host sync, unlike counts[mask] = 0
                 self.num_tokens_in_step = 0
-                for fired in self.did_fire.values():
+                for fired in self._did_fire.values():
                     fired.zero_()
         self.global_step += 1
         return self.last_fvu

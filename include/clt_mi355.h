@@ -107,6 +107,37 @@ int clt_decode_bwd_acts(const int64_t* idx, const void* v, int v_dtype, const fl
                         const void* G, int g_dtype, float* grad_acts, int accumulate_grad_acts, float* e_post,
                         float* e_scale, int64_t N, int k, clt_stream_t stream);
 
+/* CLT fan-out in one launch (runner.py:43-71: the target layer's prediction is the sum of the decodes of EVERY
+ * live source layer; sparse_coder.py:171-176 picks each source's slot).  All sources share N, k, M, d and the
+ * dtypes; `h_sources` is a HOST array of n_sources <= CLT_DECODE_MAX_SOURCES descriptors (copied into the kernel
+ * arguments: nothing is retained).  One wave per token walks the entries of all sources as one list, so a latent
+ * shard that owns only k/tp entries per source still keeps 8 row gathers in flight, and the output row is
+ * written (or the gradient row read) once per target instead of once per (source, target) pair.
+ *   fwd:  out[n,:] = (ACCUMULATE ? out[n,:] : 0) + bias + sum_s weight_s * sum_j a'_s[n,j] * W_s[idx_s[n,j],:]
+ *         (fp32 accumulation over all sources, ONE rounding to out_dtype; acts_out_s receives a'_s)
+ *   bwd:  as clt_decode_bwd_acts per source with G replaced by weight_s * G (weight: 1, or 1/divide_by of
+ *         runner.py:46-49 for the other sources when divide_cross_layer is set).                            */
+#define CLT_DECODE_MAX_SOURCES 16
+typedef struct clt_decode_source {
+  const int64_t* idx;      /* [N,k] */
+  const void* v;           /* [N,k] v_dtype */
+  const float* post_enc;   /* [M] or NULL */
+  const float* post_scale; /* [M] or NULL */
+  const void* W;           /* [M,d] w_dtype: rows [lat_begin, lat_begin + M) of the source's table for this target */
+  float* acts_out;         /* fwd: [N,k] or NULL */
+  float* grad_acts;        /* bwd: [N,k] */
+  float* e_post;           /* bwd: [N,k] or NULL */
+  float* e_scale;          /* bwd: [N,k] or NULL (requires post_scale) */
+  int64_t lat_begin;
+  float weight;
+  int32_t accumulate_grad_acts;
+} clt_decode_source;
+int clt_decode_fwd_multi(const clt_decode_source* h_sources, int n_sources, int v_dtype, int w_dtype, int64_t M, int d,
+                         const float* bias, void* out, int out_dtype, int flags, int64_t N, int k,
+                         clt_stream_t stream);
+int clt_decode_bwd_acts_multi(const clt_decode_source* h_sources, int n_sources, int v_dtype, int w_dtype, int64_t M,
+                              int d, const void* G, int g_dtype, int64_t N, int k, clt_stream_t stream);
+
 /* ------------------------------------------------------------------ segments
  * Stable sort of the N*k (token, slot) entries by latent: replaces the COO sort of
  * kernels.py:42-51 and the count/cumsum/reverse-map kernels of xformers.py:93-122,

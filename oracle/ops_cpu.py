@@ -74,6 +74,32 @@ def decode_bwd_acts(idx, v, W, G, *, post_enc=None, post_scale=None, grad_acts=N
     return grad_acts, e_post, e_scale
 
 
+def decode_fwd_multi(sources, *, bias=None, out=None, out_dtype=None, accumulate=False, round_acts=False,
+                     want_acts=False):
+    """fp32 sum over all sources, one rounding (clt_decode_fwd_multi)."""
+    W0 = sources[0]["W"]
+    total = torch.zeros(sources[0]["idx"].shape[0], W0.shape[1])
+    acts = []
+    for s in sources:
+        y, a = decode_fwd(s["idx"], s["v"], s["W"], post_enc=s.get("post_enc"), post_scale=s.get("post_scale"),
+                          out_dtype=torch.float32, round_acts=round_acts, want_acts=True, lat_begin=s.get("lat_begin", 0))
+        total = total + y.float() * s.get("weight", 1.0)
+        acts.append(a)
+    if bias is not None:
+        total = total + bias
+    if accumulate:
+        out.copy_((out.float() + total).to(out.dtype))
+    else:
+        out = total.to(out_dtype or W0.dtype)
+    return (out, acts) if want_acts else out
+
+
+def decode_bwd_acts_multi(sources, G):
+    return [decode_bwd_acts(s["idx"], s["v"], s["W"], G.float() * s.get("weight", 1.0), post_enc=s.get("post_enc"),
+                            post_scale=s.get("post_scale"), grad_acts=s.get("grad_acts"),
+                            want_e_post=s.get("want_e_post", False), lat_begin=s.get("lat_begin", 0)) for s in sources]
+
+
 def segments_build(idx, M, lat_begin=0):
     r = idx.reshape(-1) - lat_begin
     key = torch.where((r >= 0) & (r < M), r, torch.full_like(r, M))

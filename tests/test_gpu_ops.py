@@ -86,6 +86,64 @@ def test_decode_fused_random(ops, dtype, N, d, M, k):
     torch.testing.assert_close(rs.cpu(), rs_ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,d,M,k,ns,shard", [(130, 768, 2048, 32, 5, None), (67, 768, 1024, 32, 12, (256, 512)),
+                                              (9, 2048, 512, 64, 3, None), (21, 104, 300, 70, 2, (100, 200)),
+                                              (5, 64, 128, 8, 19, (0, 64))])
+def test_decode_multi_source(ops, dtype, N, d, M, k, ns, shard):
+    """clt_decode_fwd_multi / clt_decode_bwd_acts_multi == the per-source kernels summed (and the oracle); with a
+    latent shard, only the entries of rows [lo, hi) count.  ns = 19 exceeds CLT_DECODE_MAX_SOURCES (two launches)."""
+    g = torch.Generator().manual_seed(N * ns + d)
+    lo, hi = shard or (0, M)
+    Ml = hi - lo
+    tol = FP32 if dtype == torch.float32 else BF16
+    srcs, ref_y, ref = [], torch.zeros(N, d), []
+    G = torch.randn(N, d, generator=g).to(dtype)
+    for s_i in range(ns):
+        W = (torch.randn(M, d, generator=g) / math.sqrt(d)).to(dtype)
+        v = torch.rand(N, k, generator=g)
+        v[:, ::7] = 0.0
+        idx = torch.stack([torch.randperm(M, generator=g)[:k] for _ in range(N)])
+        pe = 0.1 * torch.randn(M, generator=g)
+        ps = 1 + 0.1 * torch.randn(M, generator=g)
+        weight = 1.0 if s_i == ns - 1 else 0.25
+        own = (idx >= lo) & (idx < hi)
+        a = O.post_affine_fwd(v, idx, pe, ps) * own
+        ref_y += weight * O.decode_fwd(idx, a, W.float())
+        _, ga_ref = O.decode_bwd(idx, a, W.float(), G.float() * weight)
+        u_ref, _, _ = O.post_affine_bwd(v, idx, pe, ps, ga_ref * own)
+        acc0 = torch.randn(N, k, generator=g)
+        ref.append((a, acc0, u_ref * own))
+        srcs.append(dict(idx=idx.to(DEV), v=v.to(DEV), W=W[lo:hi].contiguous().to(DEV), post_enc=pe[lo:hi].contiguous().to(DEV),
+                         post_scale=ps[lo:hi].contiguous().to(DEV), lat_begin=lo, weight=weight))
+    bias = torch.randn(d, generator=g)
+    y, acts = ops.decode_fwd_multi(srcs, bias=bias.to(DEV), want_acts=True)
+    assert y.dtype == dtype
+    torch.testing.assert_close(y.float().cpu(), ref_y + bias, **tol)
+    for (a, _, _), got in zip(ref, acts):
+        torch.testing.assert_close(got.cpu(), a, **FP32)
+    # per-source kernels, fp32 output, summed the same way
+    y1 = torch.zeros(N, d, device=DEV)
+    for s_ in srcs:
+        y1 += s_["weight"] * ops.decode_fwd(s_["idx"], s_["v"], s_["W"], post_enc=s_["post_enc"], post_scale=s_["post_scale"],
+                                            lat_begin=lo, out_dtype=torch.float32)
+    yf = ops.decode_fwd_multi(srcs, out_dtype=torch.float32)
+    torch.testing.assert_close(yf, y1, rtol=1e-5, atol=1e-5)
+    # accumulate into an existing output
+    y2 = ops.decode_fwd_multi(srcs, out=yf.clone(), accumulate=True)
+    torch.testing.assert_close(y2, 2 * yf, rtol=1e-6, atol=1e-6)
+    # backward
+    outs = ops.decode_bwd_acts_multi([dict(s_, grad_acts=r[1].to(DEV), want_e_post=True) for s_, r in zip(srcs, ref)], G.to(DEV))
+    for s_, (a, acc0, u_ref), (ga, e_post, e_scale) in zip(srcs, ref, outs):
+        torch.testing.assert_close(ga.cpu(), acc0 + u_ref, rtol=1e-4, atol=1e-4)
+        Gs = (G.float() * s_["weight"]).to(DEV)
+        ga1, ep1, es1 = ops.decode_bwd_acts(s_["idx"], s_["v"], s_["W"], Gs, post_enc=s_["post_enc"], post_scale=s_["post_scale"],
+                                            grad_acts=acc0.to(DEV), want_e_post=True, lat_begin=lo)
+        torch.testing.assert_close(ga, ga1, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(e_post, ep1, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(e_scale, es1, rtol=1e-4, atol=1e-5)
+
+
 def test_segments_skewed(ops):
     """One latent active on every token (long segment) + many empty latents."""
     N, k, M, d = 700, 8, 512, 64
