@@ -72,10 +72,18 @@ class Adam(torch.optim.Optimizer):
                 cs.append(starts)
             ct = torch.from_numpy(np.concatenate(ct)).to(dev)
             cs = torch.from_numpy(np.concatenate(cs)).to(dev)
-            host = torch.empty(len(live) * C.sizeof(_lib.AdamTensor), dtype=torch.uint8).pin_memory()
-            devt = torch.empty_like(host, device=dev)
-            tb = self._tables[key] = (ct, cs, host, devt)
-        ct, cs, host, devt = tb
+            # The upload below is asynchronous and the host may run several steps ahead of the GPU: a ring of pinned
+            # staging buffers, each guarded by an event recorded after its copy, so that a buffer is never rewritten
+            # (next step's lr, new .grad pointers) before the copy that reads it has executed.
+            nbytes = len(live) * C.sizeof(_lib.AdamTensor)
+            ring = [[torch.empty(nbytes, dtype=torch.uint8).pin_memory(), None] for _ in range(4)]
+            devt = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            tb = self._tables[key] = (ct, cs, ring, devt)
+        ct, cs, ring, devt = tb
+        slot = ring[self._step % len(ring)]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        host = slot[0]
         recs = (_lib.AdamTensor * len(live)).from_address(host.data_ptr())
         for ti, (gi, p) in enumerate(live):
             g = p.grad
@@ -89,6 +97,8 @@ class Adam(torch.optim.Optimizer):
             r.lr = float(self.param_groups[gi]["lr"])
             r.p_dtype, r.g_dtype = _DT[p.dtype], _DT[g.dtype]
         devt.copy_(host, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
         _call("clt_adam_step", C.c_void_p(devt.data_ptr()), len(live), C.c_void_p(ct.data_ptr()),
               C.c_void_p(cs.data_ptr()), ct.numel(), CHUNK, 1.0, float(betas[0]), float(betas[1]), float(eps),
               self._step, _stream(devt))

@@ -121,6 +121,13 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// a * b rounded to fp32 on its own: never contracted into an fma with a following add (hipcc contracts by default;
+// __fmul_rn is a plain product in this toolchain).  For sums that must match a product stored by another kernel.
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

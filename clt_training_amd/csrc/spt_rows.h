@@ -1,0 +1,357 @@
+// Row pass over prebuilt segments, shared by segments.hip (clt_spt_dense, clt_spt_dense_adam) and decode_rows.hip
+// (clt_decode_bwd_rows*): one wave owns RW consecutive rows of an [M, d] table.
+#pragma once
+#include <math.h>
+
+#include "common.h"
+
+namespace clt {
+
+template <typename OT, int E>
+__device__ __forceinline__ void store_row_chunk(OT* p, const float (&a)[E]) {
+  if constexpr (sizeof(OT) == 2 && E == 8) {
+    nt_store8(p, a);  // the gradient is read back once, by the optimizer, after every other kernel of the step
+  } else if constexpr (sizeof(OT) == 4 && E == 4) {
+    Chunk<float>::store(p, a);
+  } else if constexpr (sizeof(OT) == 4 && E == 8) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(a[0], a[1], a[2], a[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(a[4], a[5], a[6], a[7]);
+  } else {
+    uint2 u2;
+    u2.x = pack_bf16x2(a[0], a[1]);
+    u2.y = pack_bf16x2(a[2], a[3]);
+    *reinterpret_cast<uint2*>(p) = u2;
+  }
+}
+
+// One wave owns RW consecutive output rows.  Their segment bounds (one load) and all their entries (one
+// 64-lane load per 64 entries: entry id, weight, source row, owning output row) are fetched up front, so the
+// dependent chain offsets -> perm -> dense row is paid once per RW rows instead of once per row; the gathers of
+// consecutive output rows then issue back to back (most rows hold 0-8 entries).  Rows are finished in order:
+// when the owning row of the next entry changes, the accumulator is stored (zeros for empty rows) and cleared.
+// RW = 8 when there are rows to spare (M / 8 waves still fill the chip); fewer rows per wave when the table is
+// short and its rows long (a latent shard of a large token batch: M / tp rows, N * k / M * tp entries each).
+// The summation order within a row does not depend on RW: results are bitwise the same.
+static int pick_rw(int64_t M) { return M >= 8 * 8192 ? 8 : M >= 4 * 8192 ? 4 : M >= 2 * 8192 ? 2 : 1; }
+
+// Optimizer state of the rows for the fused variant (clt_spt_dense_adam): the finished gradient row never goes
+// to memory; it is rounded to the parameter dtype (as the .grad tensor would be) and consumed on the spot by
+// the same update arithmetic as adam.hip.
+struct AdamRows {
+  void* m;
+  void* v;
+  float step_size, b1, b2, inv_sqrt_bc2, eps;
+};
+
+// The same host arithmetic as clt_adam_step (adam.hip): bias corrections in double, one rounding each.
+static inline AdamRows make_adam_rows(void* m, void* v, float lr, float b1, float b2, float eps, int step) {
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  AdamRows ad;
+  ad.m = m;
+  ad.v = v;
+  ad.step_size = lr * 1.0f * (float)(1.0 / bc1);
+  ad.b1 = b1;
+  ad.b2 = b2;
+  ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  ad.eps = eps;
+  return ad;
+}
+
+// Decoder backward in the same row pass (clt_decode_bwd_rows*): the table row IS the decoder row W[r,:], the
+// gathered dense rows are the loss gradient G[n,:], so the gradient wrt the bag weight of entry e = (n, j),
+//   ga = G[n,:] . W[r,:]                                             (xformers.py:167-171),
+// costs one dot product against registers that are already loaded -- no second gather of W rows per token.  The
+// backward of the post-encoder affine (sparse_coder.py:136-140) and its per-latent sums follow on the spot.
+struct BwdActs {
+  const void* v;            // [N*k] top-k values (v_dtype): the (v > 0) mask and d post_enc_scale
+  int v_dtype;
+  const float* post_enc;    // [M] or null
+  const float* post_scale;  // [M] or null
+  float* grad_acts;         // [N*k] fp32, accumulated into (the detached leaf's .grad, sparse_coder.py:72-76)
+  float* g_post;            // [M] or null:  sum_e u * (v > 0)
+  float* g_scale;           // [M] or null:  sum_e ga * (v + post_enc * (v > 0))
+  const void* W;            // [M, d] table rows when they are not the Adam parameter (plain gradient output)
+};
+
+template <typename PT, int E>
+__device__ __forceinline__ void load_row_chunk(const PT* p, float (&a)[E]) {
+  if constexpr (sizeof(PT) == 2 && E == 8) {
+    nt_load8(p, a);
+  } else if constexpr (sizeof(PT) == 4) {
+#pragma unroll
+    for (int q = 0; q < E; q += 4) {
+      const float4 f = *reinterpret_cast<const float4*>(p + q);
+      a[q] = f.x; a[q + 1] = f.y; a[q + 2] = f.z; a[q + 3] = f.w;
+    }
+  } else {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    a[0] = bf16_lo(u.x); a[1] = bf16_hi(u.x); a[2] = bf16_lo(u.y); a[3] = bf16_hi(u.y);
+  }
+}
+
+template <typename DT, typename OT, int CH, int U, bool ADAM, int RW, bool BWD = false>
+__global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ offsets, int64_t M,
+                                                        const float* __restrict__ vals,
+                                                        const void* __restrict__ gate, int gate_dtype,
+                                                        const DT* __restrict__ dense, int d, int k,
+                                                        OT* __restrict__ out, float* __restrict__ rowsum,
+                                                        const AdamRows ad, const BwdActs bw = BwdActs()) {
+  constexpr int E = Chunk<DT>::E;
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (r0 >= M) return;
+  const int nrows = (int)min((int64_t)RW, M - r0);
+  const int nchunks = d / E;
+  const int my_off = lane <= nrows ? offsets[r0 + lane] : 0;  // lanes 0..nrows hold the RW+1 bounds
+  const int beg = readlane_i(my_off, 0), end = readlane_i(my_off, nrows);
+  // The row bounds as wave-uniform values, read HERE, in uniform control flow.  A v_readlane inside the divergent
+  // `if (pos < end)` below may name a lane that is inactive there, and under register pressure hipcc spills and
+  // restores my_off around such a region for the active lanes only: the inactive lanes then hold garbage and rows
+  // with few entries landed on neighbouring rows (d = 4096: the fused variants need > 256 VGPRs).
+  int bnd[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) bnd[q] = q < nrows ? readlane_i(my_off, q) : 0x7fffffff;
+
+  float acc[CH][E];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+  float rs = 0.f;   // wave-uniform row sum
+  int cur = 0;      // row (relative to r0) being accumulated
+  // BWD: per-row post-encoder parameters (lane q holds row q's), the running per-row sums, and -- when the row is
+  // not prefetched as optimizer state -- the table row itself, loaded at the row's first entry
+  float pe_l = 0.f, ps_l = 1.f, pe_cur = 0.f, ps_cur = 1.f, gp_acc = 0.f, gs_acc = 0.f;
+  float wrow[BWD ? CH : 1][E];
+  int wrow_of = -1;
+  if constexpr (BWD) {
+    if (lane < nrows) {
+      if (bw.post_enc) pe_l = bw.post_enc[r0 + lane];
+      if (bw.post_scale) ps_l = bw.post_scale[r0 + lane];
+    }
+    pe_cur = readlane_f(pe_l, 0);
+    ps_cur = readlane_f(ps_l, 0);
+  }
+
+  // Fused optimizer variant: the parameter / exp_avg / exp_avg_sq chunks of the row being accumulated are fetched
+  // when the row STARTS (16 bytes per lane and chunk each), so they are in flight behind the row's gathers and
+  // the next row's fetch is issued before the current row's update arithmetic.
+  constexpr bool PREFETCH = ADAM && sizeof(OT) * E == 16;
+  u32x4 pq[PREFETCH ? CH : 1], mq[PREFETCH ? CH : 1], vq[PREFETCH ? CH : 1];
+  auto prefetch_chunk = [&](int row, int c) {
+    if constexpr (PREFETCH) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) {
+        const int64_t off = (r0 + row) * (int64_t)d + ch * E;
+        pq[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(out + off));
+        mq[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const OT*>(ad.m) + off));
+        vq[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const OT*>(ad.v) + off));
+      }
+    }
+  };
+  auto unpack = [&](const u32x4& u, float (&f)[E]) {
+    if constexpr (sizeof(OT) == 2) {
+      f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+      if constexpr (E == 8) {
+        f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+      }
+    } else {
+      f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < CH; ++c) prefetch_chunk(0, c);
+
+  auto flush_until = [&](int upto) {  // store rows cur .. upto-1 (wave-uniform loop)
+    while (cur < upto) {
+      OT* orow = out + (r0 + cur) * (int64_t)d;
+      if constexpr (ADAM) {
+        const bool more = cur + 1 < nrows;  // wave-uniform
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            const int64_t off = (r0 + cur) * (int64_t)d + ch * E;
+            OT* mrow = reinterpret_cast<OT*>(ad.m) + off;
+            OT* vrow = reinterpret_cast<OT*>(ad.v) + off;
+            float pf[E], mf[E], vf[E];
+            if constexpr (PREFETCH) {
+              unpack(pq[c], pf);
+              unpack(mq[c], mf);
+              unpack(vq[c], vf);
+              if (more) prefetch_chunk(cur + 1, c);  // the next row's chunk, behind this row's arithmetic
+            } else {
+              load_row_chunk<OT, E>(orow + ch * E, pf);
+              load_row_chunk<OT, E>(mrow, mf);
+              load_row_chunk<OT, E>(vrow, vf);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const float g = sizeof(OT) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+              mf[e] = mf[e] + (g - mf[e]) * (1.f - ad.b1);
+              vf[e] = ad.b2 * vf[e] + (1.f - ad.b2) * g * g;
+              const float denom = sqrtf(vf[e]) * ad.inv_sqrt_bc2 + ad.eps;
+              pf[e] = pf[e] - ad.step_size * (mf[e] / denom);
+              acc[c][e] = 0.f;
+            }
+            store_row_chunk<OT, E>(orow + ch * E, pf);
+            store_row_chunk<OT, E>(mrow, mf);
+            store_row_chunk<OT, E>(vrow, vf);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            store_row_chunk<OT, E>(orow + ch * E, acc[c]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+          }
+        }
+      }
+      if (rowsum && lane == 0) rowsum[r0 + cur] = rs;
+      rs = 0.f;
+      if constexpr (BWD) {
+        if (lane == 0) {
+          if (bw.g_post) bw.g_post[r0 + cur] = gp_acc;
+          if (bw.g_scale) bw.g_scale[r0 + cur] = gs_acc;
+        }
+        gp_acc = gs_acc = 0.f;
+      }
+      ++cur;
+      if constexpr (BWD) {
+        if (cur < nrows) {
+          pe_cur = readlane_f(pe_l, cur);
+          ps_cur = readlane_f(ps_l, cur);
+        }
+      }
+    }
+  };
+
+  for (int s0 = beg; s0 < end; s0 += 64) {
+    int my_n = 0, my_row = 0, my_e = 0;
+    float my_w = 0.f, my_v = 0.f, my_u = 0.f;
+    const int pos = s0 + lane;
+    if (pos < end) {
+      const int e = perm[pos];
+      my_e = e;
+      if constexpr (BWD) my_v = load_scalar(bw.v, bw.v_dtype, e);
+      float w = vals[e];
+      if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
+      my_w = w;
+      my_n = e / k;
+#pragma unroll
+      for (int q = 1; q < RW; ++q) my_row += pos >= bnd[q] ? 1 : 0;
+    }
+    const int cnt = min(64, end - s0);
+    for (int jj = 0; jj < cnt; jj += U) {
+      uint4 raw[U][CH];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jl = min(jj + u, cnt - 1);
+        const int n = readlane_i(my_n, jl);
+        const char* row = reinterpret_cast<const char*>(dense) + (size_t)n * (size_t)d * sizeof(DT);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (jj + u < cnt) {  // wave-uniform
+          const int row_e = readlane_i(my_row, jj + u);
+          const float w = readlane_f(my_w, jj + u);
+          if (row_e != cur) flush_until(row_e);
+          rs += w;
+          if constexpr (BWD && !PREFETCH) {
+            if (wrow_of != row_e) {  // wave-uniform: the row's first entry
+              const OT* wsrc = (ADAM ? out : reinterpret_cast<const OT*>(bw.W)) + (r0 + row_e) * (int64_t)d;
+#pragma unroll
+              for (int c = 0; c < CH; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nchunks) load_row_chunk<OT, E>(wsrc + ch * E, wrow[c]);
+              }
+              wrow_of = row_e;
+            }
+          }
+          float part = 0.f;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+              float x[E];
+              Chunk<DT>::expand(raw[u][c], x);
+#pragma unroll
+              for (int e = 0; e < E; ++e) acc[c][e] = fmaf(w, x[e], acc[c][e]);
+              if constexpr (BWD) {
+                if constexpr (PREFETCH) {
+                  float wv[E];
+                  unpack(pq[c], wv);  // the parameter row before this step's update
+#pragma unroll
+                  for (int e = 0; e < E; ++e) part = fmaf(x[e], wv[e], part);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < E; ++e) part = fmaf(x[e], wrow[c][e], part);
+                }
+              }
+            }
+          }
+          if constexpr (BWD) {
+            part = wave_sum(part);  // ga of this entry, in every lane
+            const float v_e = readlane_f(my_v, jj + u);
+            const float posf = v_e > 0.f ? 1.f : 0.f;
+            const float u_ = bw.post_scale ? part * ps_cur : part;
+            // products rounded before they are added (no fma contraction): the sums are bitwise those of
+            // clt_decode_bwd_acts -> clt_segment_sum
+            gs_acc += mul_rounded(part, v_e + pe_cur * posf);
+            gp_acc += mul_rounded(u_, posf);
+            if (lane == jj + u) my_u = u_;
+          }
+        }
+      }
+    }
+    if constexpr (BWD) {
+      if (pos < end) bw.grad_acts[my_e] += my_u;  // every entry belongs to exactly one row: no conflicts
+    }
+  }
+  flush_until(nrows);
+}
+
+template <typename DT, typename OT, bool ADAM = false, bool BWD = false>
+static int launch_spt(int ch, hipStream_t st, const int32_t* perm, const int32_t* offsets, int64_t M,
+                      const float* vals, const void* gate, int gate_dtype, const void* dense, int d, int k, void* out,
+                      float* rowsum, AdamRows ad = AdamRows(), BwdActs bw = BwdActs()) {
+  const int rw = pick_rw(M);
+  const dim3 grid((unsigned)((M + 4 * rw - 1) / (4 * rw)));
+#define LAUNCH_RW(CH, U, RW_)                                                                                         \
+  hipLaunchKernelGGL((spt_dense_kernel<DT, OT, CH, U, ADAM, RW_, BWD>), grid, dim3(256), 0, st, perm, offsets, M,     \
+                     vals, gate, gate_dtype, (const DT*)dense, d, k, (OT*)out, rowsum, ad, bw)
+#define LAUNCH(CH, U)                    \
+  do {                                   \
+    if (rw == 8) LAUNCH_RW(CH, U, 8);    \
+    else if (rw == 4) LAUNCH_RW(CH, U, 4); \
+    else if (rw == 2) LAUNCH_RW(CH, U, 2); \
+    else LAUNCH_RW(CH, U, 1);            \
+  } while (0)
+  switch (ch) {
+    case 1: LAUNCH(1, 8); break;
+    case 2:
+      if (ADAM) { LAUNCH(2, 4); }  // fewer gathers in flight, more waves: the state streams need the occupancy
+      else { LAUNCH(2, 8); }
+      break;
+    case 4: LAUNCH(4, 4); break;
+    case 8: LAUNCH(8, 2); break;
+    case 16: LAUNCH(16, 1); break;
+    default: return CLT_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH
+#undef LAUNCH_RW
+  return CLT_OK;
+}
+
+
+}  // namespace clt

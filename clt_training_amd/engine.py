@@ -30,6 +30,7 @@ under gloo.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -360,8 +361,14 @@ class CLTEngine:
         G_r_div = G_r if div == 1 else (G_r.float() / div).to(cd)
         gb = G_r.sum(0, dtype=torch.float32)  # d b_dec: the same column sums for every live source (x 1/div)
         gWs = (G_r.mT @ X_live) if X_live is not None else None  # [d, n_live*d]: block i is d W_skip of source i
+        # Decoder backward.  Preferred: ONE row pass per (source, target) pair (ops.decode_bwd_rows) that yields the
+        # weight-gradient rows (consumed by the Adam update on the spot when the optimizer allows it), the gradient
+        # wrt the activations and the post-encoder sums -- no second gather of decoder rows per token.  Otherwise:
+        # the gradient wrt the activations of every live source in one launch, then grad-W rows and segment sums.
+        rows_pass = (hasattr(ops, "decode_bwd_rows") and all(w.dtype == G.dtype for w in Wt)
+                     and not os.environ.get("CLT_NO_ROWS_PASS"))  # (the switch is for A/B timing only)
         bwd_multi = None
-        if multi and hasattr(ops, "decode_bwd_acts_multi"):  # grad wrt the activations of every live source: ONE launch
+        if not rows_pass and multi and hasattr(ops, "decode_bwd_acts_multi"):  # grad wrt the activations of every live source: ONE launch
             srcs = []
             for st, sc_ in zip(self.live, scale):
                 li = self.coders[st.layer]
@@ -385,21 +392,32 @@ class CLTEngine:
                     self._acc_grad(li.W_skips[t], (Gi_r.mT @ st.xn_r).float())
             ps = li.post_enc_scales[t] if li.post_enc_scales is not None else None
             need_pe = li.post_encs[t].requires_grad
-            if bwd_multi is not None:
-                _, e_post, e_scale = bwd_multi[n_st]
-            else:
-                _, e_post, e_scale = ops.decode_bwd_acts(st.idx, st.v, li.W_decs[t], Gi, post_enc=li.post_encs[t],
-                                                         post_scale=ps, grad_acts=st.gv, want_e_post=need_pe,
-                                                         lat_begin=li.lat_begin)
             if st.seg is None:
                 st.seg = ops.segments_build(st.idx, li.m_local, lat_begin=li.lat_begin)
-            self._grad_rows(li.W_decs[t], st.seg, st.acts.pop(t).view(-1), Gi, acc_steps)
+            if rows_pass:
+                W = li.W_decs[t]
+                h = self._fused_state(W, acc_steps)
+                gW, gp, gs = ops.decode_bwd_rows(st.seg, st.acts.pop(t).view(-1), st.v, W.data, Gi, st.gv,
+                                                 post_enc=li.post_encs[t], post_scale=ps, want_g_post=need_pe, adam=h)
+                if gW is not None:
+                    self._acc_grad(W, gW)
+            else:
+                if bwd_multi is not None:
+                    _, e_post, e_scale = bwd_multi[n_st]
+                else:
+                    _, e_post, e_scale = ops.decode_bwd_acts(st.idx, st.v, li.W_decs[t], Gi, post_enc=li.post_encs[t],
+                                                             post_scale=ps, grad_acts=st.gv, want_e_post=need_pe,
+                                                             lat_begin=li.lat_begin)
+                self._grad_rows(li.W_decs[t], st.seg, st.acts.pop(t).view(-1), Gi, acc_steps)
+                gp = gs = None
+                if need_pe:
+                    if ps is not None and ps.requires_grad:
+                        gp, gs = ops.segment_sum(st.seg, e_post.view(-1), e_scale.view(-1))
+                    else:
+                        gp, _ = ops.segment_sum(st.seg, e_post.view(-1))
             if need_pe:
                 if ps is not None and ps.requires_grad:
-                    gp, gs = ops.segment_sum(st.seg, e_post.view(-1), e_scale.view(-1))
                     self._acc_grad(ps, gs)
-                else:
-                    gp, _ = ops.segment_sum(st.seg, e_post.view(-1))
                 self._acc_grad(li.post_encs[t], gp)
 
         # ---------------- advance; deferred encoder backward (runner.py:56-59,193-197; fused_encoder.py:92-155)
@@ -423,6 +441,14 @@ class CLTEngine:
         self.last_fvu[j] = fvu
         self.last_idx[j] = idx  # merged global indices (fired-latent bookkeeping, trainer.py:622-628)
         return fvu
+
+    def _fused_state(self, p: Tensor, acc_steps: int):
+        """Optimizer state / hyper-parameters for applying this step's update of ``p`` inside the gradient kernel, or
+        None when the gradient has another consumer (accumulation over micro-steps, an existing .grad, no optimizer)."""
+        fo = self.fused_opt
+        if fo is None or acc_steps != 1 or p.grad is not None:
+            return None
+        return fo.fused_rows(p)
 
     def _grad_rows(self, p: Tensor, seg, vals: Tensor, dense: Tensor, acc_steps: int, gate: Optional[Tensor] = None,
                    want_rowsum: bool = False):

@@ -315,6 +315,38 @@ def spt_dense_adam(seg: Segments, vals: Tensor, dense: Tensor, p: Tensor, m: Ten
     return rowsum
 
 
+def decode_bwd_rows(seg: Segments, acts: Tensor, v: Tensor, W: Tensor, G: Tensor, grad_acts: Tensor, *,
+                    post_enc: Optional[Tensor] = None, post_scale: Optional[Tensor] = None, want_g_post: bool = False,
+                    adam: Optional[dict] = None):
+    """Decoder backward of one (source, target) pair in one row pass (clt_decode_bwd_rows / _adam): weight-gradient
+    rows (returned, or consumed by the Adam update when ``adam`` = dict(m, v, lr, betas, eps, step) is given), the
+    gradient wrt the activations accumulated into ``grad_acts`` and the post-encoder sums.
+    Returns (grad_W or None, g_post or None, g_scale or None)."""
+    acts, v, G = _c(acts), _c(v), _c(G)
+    M, d = W.shape
+    assert acts.dtype == torch.float32 and acts.numel() == seg.perm.numel() == v.numel() == grad_acts.numel()
+    assert W.is_contiguous() and M == seg.M and G.shape[1] == d and G.dtype == W.dtype
+    assert grad_acts.dtype == torch.float32 and grad_acts.is_contiguous()
+    for t in (post_enc, post_scale):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    g_post = torch.empty(M, dtype=torch.float32, device=W.device) if want_g_post else None
+    g_scale = torch.empty(M, dtype=torch.float32, device=W.device) if post_scale is not None else None
+    head = (_ptr(seg.perm), _ptr(seg.offsets), M, _ptr(acts), _ptr(v), _dt(v), _ptr(post_enc), _ptr(post_scale), _ptr(G),
+            _dt(G), d, seg.k)
+    if adam is None:
+        gW = torch.empty(M, d, dtype=W.dtype, device=W.device)
+        _call("clt_decode_bwd_rows", *head, _ptr(W), _dt(W), _ptr(gW), _ptr(grad_acts), _ptr(g_post), _ptr(g_scale),
+              _stream(W))
+        return gW, g_post, g_scale
+    m_, v_ = adam["m"], adam["v"]
+    assert m_.dtype == W.dtype and v_.dtype == W.dtype and m_.shape == W.shape and v_.shape == W.shape
+    assert m_.is_contiguous() and v_.is_contiguous()
+    _call("clt_decode_bwd_rows_adam", *head, _ptr(W), _ptr(m_), _ptr(v_), _dt(W), _ptr(grad_acts), _ptr(g_post),
+          _ptr(g_scale), float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]), float(adam["eps"]),
+          int(adam["step"]), _stream(W))
+    return None, g_post, g_scale
+
+
 def segment_sum(seg: Segments, a: Tensor, b: Optional[Tensor] = None):
     a = _c(a)
     assert a.dtype == torch.float32

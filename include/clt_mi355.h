@@ -175,6 +175,28 @@ int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, int64_t M, c
                        int p_dtype, float* rowsum, float lr, float b1, float b2, float eps, int step,
                        clt_stream_t stream);
 
+/* Decoder backward of one (source, target) pair as ONE row pass: the weight gradient of clt_spt_dense (xformers.py:
+ * 125-166), the gradient wrt the bag weights of clt_decode_bwd_acts (xformers.py:167-171) and the per-latent sums
+ * of clt_segment_sum together.  For every decoder row r and every entry e = (n, j) of its segment:
+ *   grad_W[r,:] += acts[e] * G[n,:];   ga = G[n,:] . W[r,:];   u = ga * post_scale[r]
+ *   grad_acts[e] += u;   g_post[r] += u * (v[e] > 0);   g_scale[r] += ga * (v[e] + post_enc[r] * (v[e] > 0))
+ * so the k decoder rows per token are NOT gathered a second time: the row of W is in registers when G[n,:] arrives.
+ * acts [N*k] fp32 = a' (what clt_decode_fwd reported); v [N*k] `v_dtype` = the top-k values; G [N,d] and W [M,d]
+ * share `g_dtype` == `w_dtype`; grad_acts [N*k] fp32 is ACCUMULATED into (entries of other shards are not
+ * touched: zero it before the source's first target); g_post / g_scale [M] fp32 or NULL are overwritten.
+ * clt_decode_bwd_rows writes the gradient to grad_W [M,d] (`w_dtype`); clt_decode_bwd_rows_adam consumes it in the
+ * Adam update of (W, exp_avg, exp_avg_sq) exactly as clt_spt_dense_adam does, with ga taken against the row
+ * BEFORE the update.  Results are bitwise those of the three separate entry points.                        */
+int clt_decode_bwd_rows(const int32_t* perm, const int32_t* offsets, int64_t M, const float* acts, const void* v,
+                        int v_dtype, const float* post_enc, const float* post_scale, const void* G, int g_dtype, int d,
+                        int k, const void* W, int w_dtype, void* grad_W, float* grad_acts, float* g_post,
+                        float* g_scale, clt_stream_t stream);
+int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offsets, int64_t M, const float* acts, const void* v,
+                             int v_dtype, const float* post_enc, const float* post_scale, const void* G, int g_dtype,
+                             int d, int k, void* W, void* exp_avg, void* exp_avg_sq, int w_dtype, float* grad_acts,
+                             float* g_post, float* g_scale, float lr, float b1, float b2, float eps, int step,
+                             clt_stream_t stream);
+
 /* Per-latent sums of up to two per-entry arrays (post_enc / post_enc_scale grads: the
  * scatter-adds autograd generates for sparse_coder.py:136-140):
  *   out_a[r] = sum_{e in segment r} a[e];  out_b likewise (b/out_b may be NULL).  fp32.  */

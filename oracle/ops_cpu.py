@@ -131,6 +131,31 @@ def spt_dense(seg, vals, dense, *, gate=None, out_dtype=None, want_rowsum=False,
     return res
 
 
+def decode_bwd_rows(seg, acts, v, W, G, grad_acts, *, post_enc=None, post_scale=None, want_g_post=False, adam=None):
+    """The three separate ops in sequence (clt_decode_bwd_rows); the CPU double has no fused optimizer."""
+    assert adam is None
+    N = G.shape[0]
+    k = seg.k
+    real = seg.perm[: int(seg.offsets[-1])]
+    rows = torch.repeat_interleave(torch.arange(seg.M), seg.offsets[1:] - seg.offsets[:-1])
+    r_of = torch.zeros(N * k, dtype=torch.long)
+    r_of[real] = rows
+    own = torch.zeros(N * k, dtype=torch.bool)
+    own[real] = True
+    ga = (W.float()[r_of] * G.float()[torch.arange(N * k) // k]).sum(-1) * own
+    vf = v.float().reshape(-1)
+    pos = (vf > 0).float()
+    u = ga * post_scale[r_of] if post_scale is not None else ga
+    grad_acts.view(-1).add_(u * own)
+    g_post = torch.zeros(seg.M).index_add_(0, r_of[real], (u * pos)[real]) if want_g_post else None
+    g_scale = None
+    if post_scale is not None:
+        es = ga * (vf + (post_enc[r_of] * pos if post_enc is not None else 0))
+        g_scale = torch.zeros(seg.M).index_add_(0, r_of[real], es[real])
+    gW = spt_dense(seg, acts.reshape(-1), G, out_dtype=W.dtype)
+    return gW, g_post, g_scale
+
+
 def segment_sum(seg, a, b=None):
     e, rows = _scatter(seg, a)
     oa = torch.zeros(seg.M).index_add_(0, rows, a.float()[e])

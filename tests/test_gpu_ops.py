@@ -144,6 +144,68 @@ def test_decode_multi_source(ops, dtype, N, d, M, k, ns, shard):
         torch.testing.assert_close(e_scale, es1, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,d,M,k,shard,scale", [(300, 768, 1024, 32, None, True), (1500, 768, 512, 32, (128, 384), True),
+                                                 (64, 2048, 4096, 64, None, False), (19, 104, 300, 70, (100, 200), True),
+                                                 (40, 4096, 70000, 16, None, True), (64, 768, 20000, 32, None, True),
+                                                 (64, 768, 40000, 32, None, False), (50, 768, 70000, 16, None, True),
+                                                 (40, 2048, 70000, 16, None, True)])
+def test_decode_bwd_rows_equals_separate_kernels(ops, dtype, N, d, M, k, shard, scale):
+    """clt_decode_bwd_rows(_adam) == clt_decode_bwd_acts + clt_segment_sum + clt_spt_dense(_adam), bit for bit
+    (same dot-product and summation order), with and without a latent shard; every rows-per-wave variant
+    (table sizes 256 .. 70000)."""
+    g = torch.Generator().manual_seed(N + M)
+    lo, hi = shard or (0, M)
+    W = (torch.randn(M, d, generator=g) / math.sqrt(d)).to(dtype)[lo:hi].contiguous().to(DEV)
+    v = torch.rand(N, k, generator=g)
+    v[:, ::5] = 0.0
+    v = v.to(dtype).to(DEV)
+    idx = torch.stack([torch.randperm(M, generator=g)[:k] for _ in range(N)]).to(DEV)
+    if M == 512:
+        idx[:, 0] = 130  # one latent on every token: a long segment
+    pe = (0.1 * torch.randn(M, generator=g))[lo:hi].contiguous().to(DEV)
+    ps = (1 + 0.1 * torch.randn(M, generator=g))[lo:hi].contiguous().to(DEV) if scale else None
+    G = torch.randn(N, d, generator=g).to(dtype).to(DEV)
+    acc0 = torch.randn(N, k, generator=g).to(DEV)
+    _, acts = ops.decode_fwd(idx, v, W, post_enc=pe, post_scale=ps, want_acts=True, lat_begin=lo)
+    seg = ops.segments_build(idx, hi - lo, lat_begin=lo)
+    # separate kernels
+    ga1, e_post, e_scale = ops.decode_bwd_acts(idx, v, W, G, post_enc=pe, post_scale=ps, grad_acts=acc0.clone(),
+                                               want_e_post=True, lat_begin=lo)
+    gp1, gs1 = ops.segment_sum(seg, e_post.view(-1), e_scale.view(-1) if scale else None)
+    gW1 = ops.spt_dense(seg, acts.view(-1), G, out_dtype=dtype)
+    # one row pass
+    ga2 = acc0.clone()
+    gW2, gp2, gs2 = ops.decode_bwd_rows(seg, acts.view(-1), v, W, G, ga2, post_enc=pe, post_scale=ps, want_g_post=True)
+    assert torch.equal(gW2, gW1)
+    assert torch.equal(ga2, ga1)
+    assert torch.equal(gp2, gp1)
+    assert (gs2 is None and gs1 is None) or torch.equal(gs2, gs1)
+    # against the oracle as well
+    own = ((idx >= lo) & (idx < hi)).cpu()
+    ga_ref = (W.float().cpu()[(idx.cpu() - lo).clamp(0, hi - lo - 1)] * G.float().cpu().unsqueeze(1)).sum(-1) * own
+    u_ref = ga_ref * ps.cpu()[(idx.cpu() - lo).clamp(0, hi - lo - 1)] if scale else ga_ref
+    torch.testing.assert_close(ga2.cpu(), acc0.cpu() + u_ref, rtol=1e-4, atol=1e-4)
+    # Adam variant: parameter, moments and activation gradients as grad -> clt_adam_step / clt_spt_dense_adam
+    m1, v1, W1 = torch.zeros_like(W), torch.zeros_like(W), W.clone()
+    m2, v2, W2 = torch.zeros_like(W), torch.zeros_like(W), W.clone()
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    from clt_training_amd.adam import Adam
+    p3 = torch.nn.Parameter(W.clone())
+    opt3 = Adam([p3], **hp)
+    for step in (1, 2):
+        ops.spt_dense_adam(seg, acts.view(-1), G, W1, m1, v1, step=step, **hp)
+        p3.grad = gW1.clone()
+        opt3.step()
+        assert torch.equal(W1, p3.data)  # clt_spt_dense -> .grad -> clt_adam_step
+        ga3 = acc0.clone()
+        _, gp3, gs3 = ops.decode_bwd_rows(seg, acts.view(-1), v, W2, G, ga3, post_enc=pe, post_scale=ps, want_g_post=True,
+                                          adam=dict(m=m2, v=v2, step=step, **hp))
+        if step == 1:
+            assert torch.equal(ga3, ga1) and torch.equal(gp3, gp1)
+        assert torch.equal(W2, W1) and torch.equal(m2, m1) and torch.equal(v2, v1)
+
+
 def test_segments_skewed(ops):
     """One latent active on every token (long segment) + many empty latents."""
     N, k, M, d = 700, 8, 512, 64
