@@ -48,10 +48,7 @@ __device__ __forceinline__ void adam_chunk(PT* __restrict__ p, const GT* __restr
     }
 #pragma unroll
     for (int q = 0; q < V; ++q) {
-      mf[q] = mf[q] + (gf[q] - mf[q]) * (1.f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
-      vf[q] = b2 * vf[q] + (1.f - b2) * gf[q] * gf[q];       // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-      const float denom = sqrtf(vf[q]) * inv_sqrt_bc2 + eps;  // (sqrt(v) / sqrt(bc2)).add_(eps)
-      pf[q] = pf[q] - step_size * (mf[q] / denom);            // param.addcdiv_(m, denom, -lr / bc1)
+      adam_update(pf[q], mf[q], vf[q], gf[q], step_size, b1, b2, inv_sqrt_bc2, eps);
     }
     if constexpr (sizeof(PT) == 2 && VAR >= 1) {
       nt_store8(p + i * V, pf);
@@ -73,10 +70,7 @@ __device__ __forceinline__ void adam_chunk(PT* __restrict__ p, const GT* __restr
   // scalar tail
   for (int64_t i = nvec * V + threadIdx.x; i < n; i += 256) {
     float pf = (float)p[i], gf = (float)g[i], mf = (float)m[i], vf = (float)v[i];
-    mf = mf + (gf - mf) * (1.f - b1);
-    vf = b2 * vf + (1.f - b2) * gf * gf;
-    const float denom = sqrtf(vf) * inv_sqrt_bc2 + eps;
-    pf = pf - step_size * (mf / denom);
+    adam_update(pf, mf, vf, gf, step_size, b1, b2, inv_sqrt_bc2, eps);
     p[i] = (PT)pf;
     m[i] = (PT)mf;
     v[i] = (PT)vf;

@@ -134,4 +134,33 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// One element of torch.optim.Adam's update (trainer.py:178-186; exp_avg.lerp_, exp_avg_sq.mul_().addcmul_(),
+// param.addcdiv_()), written with explicit roundings: no contraction is left to the compiler, so every kernel that
+// applies it (clt_adam_step, clt_spt_dense_adam, clt_decode_bwd_rows_adam) produces the same bits.
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float step_size, float b1, float b2,
+                                            float inv_sqrt_bc2, float eps) {
+#pragma clang fp contract(off)
+  m = fmaf(g - m, 1.f - b1, m);
+  v = fmaf((1.f - b2) * g, g, b2 * v);
+  const float denom = fmaf(sqrtf(v), inv_sqrt_bc2, eps);
+  p = fmaf(-step_size, m / denom, p);
+}
+
+// Wave sum without the LDS crossbar: four DPP row shifts leave each row-of-16 total in its lane 15, the four row
+// totals are then added in a fixed order.  ~6x shorter dependency chain than six ds_bpermute steps.  Needs all 64
+// lanes active (call it in wave-uniform control flow).  The summation ORDER differs from wave_sum: kernels whose
+// results are compared bit for bit must use the same one.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add_<0x111>(v);  // row_shr:1 (lanes shifted in from outside the row read 0)
+  v = dpp_add_<0x112>(v);  // row_shr:2
+  v = dpp_add_<0x114>(v);  // row_shr:4
+  v = dpp_add_<0x118>(v);  // row_shr:8
+  const float a = readlane_f(v, 15), b = readlane_f(v, 31), c = readlane_f(v, 47), d = readlane_f(v, 63);
+  return ((a + b) + c) + d;
+}
+
 }  // namespace clt

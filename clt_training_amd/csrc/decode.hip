@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
             for (int e = 0; e < E; ++e) part = fmaf(g[c][e], w[e], part);
           }
         }
-        part = wave_sum(part);
+        part = wave_sum_dpp(part);
         if (jj + u < cnt && lane == jj + u) my_ga = part;
       }
     }
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_multi_kernel(const SrcTab
             for (int q = 0; q < E; ++q) part = fmaf(g[c][q], w[q], part);
           }
         }
-        part = wave_sum(part);
+        part = wave_sum_dpp(part);
         if (jj + u < cnt && lane == jj + u) my_ga = part;
       }
     }

@@ -67,7 +67,12 @@ extern "C" int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offs
   BwdActs bw = {v, v_dtype, post_enc, post_scale, grad_acts, g_post, g_scale, nullptr};
   const AdamRows ad = make_adam_rows(exp_avg, exp_avg_sq, lr, b1, b2, eps, step);
   hipStream_t st = (hipStream_t)stream;
-  if (g_dtype == CLT_BF16)
+  const bool lds_ok = rows_lds_ok(d, dtype_size(w_dtype), ch);
+  if (lds_ok && g_dtype == CLT_BF16)
+    rc = launch_rows_lds<bf16_t, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw);
+  else if (lds_ok)
+    rc = launch_rows_lds<float, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw);
+  else if (g_dtype == CLT_BF16)
     rc = launch_spt<bf16_t, bf16_t, true, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw);
   else
     rc = launch_spt<float, float, true, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw);

@@ -163,7 +163,12 @@ extern "C" int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, i
   const AdamRows ad = make_adam_rows(m, v, lr, b1, b2, eps, step);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (dense_dtype == CLT_BF16 && p_dtype == CLT_BF16)
+  const bool lds_ok = dense_dtype == p_dtype && rows_lds_ok(d, dtype_size(p_dtype), ch);
+  if (lds_ok && p_dtype == CLT_BF16)
+    rc = launch_rows_lds<bf16_t, false>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad, BwdActs());
+  else if (lds_ok)
+    rc = launch_rows_lds<float, false>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad, BwdActs());
+  else if (dense_dtype == CLT_BF16 && p_dtype == CLT_BF16)
     rc = launch_spt<bf16_t, bf16_t, true>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
   else if (dense_dtype == CLT_BF16 && p_dtype == CLT_F32)
     rc = launch_spt<bf16_t, float, true>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);

@@ -2,6 +2,7 @@
 // (clt_decode_bwd_rows*): one wave owns RW consecutive rows of an [M, d] table.
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -190,10 +191,7 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
 #pragma unroll
             for (int e = 0; e < E; ++e) {
               const float g = sizeof(OT) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
-              mf[e] = mf[e] + (g - mf[e]) * (1.f - ad.b1);
-              vf[e] = ad.b2 * vf[e] + (1.f - ad.b2) * g * g;
-              const float denom = sqrtf(vf[e]) * ad.inv_sqrt_bc2 + ad.eps;
-              pf[e] = pf[e] - ad.step_size * (mf[e] / denom);
+              adam_update(pf[e], mf[e], vf[e], g, ad.step_size, ad.b1, ad.b2, ad.inv_sqrt_bc2, ad.eps);
               acc[c][e] = 0.f;
             }
             store_row_chunk<OT, E>(orow + ch * E, pf);
@@ -238,7 +236,10 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
     if (pos < end) {
       const int e = perm[pos];
       my_e = e;
-      if constexpr (BWD) my_v = load_scalar(bw.v, bw.v_dtype, e);
+      if constexpr (BWD) {
+        my_v = load_scalar(bw.v, bw.v_dtype, e);
+        my_u = bw.grad_acts[e];  // fetched with the entry: only a store is left at the end of the chunk
+      }
       float w = vals[e];
       if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
       my_w = w;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
             }
           }
           if constexpr (BWD) {
-            part = wave_sum(part);  // ga of this entry, in every lane
+            part = wave_sum_dpp(part);  // ga of this entry, in every lane
             const float v_e = readlane_f(my_v, jj + u);
             const float posf = v_e > 0.f ? 1.f : 0.f;
             const float u_ = bw.post_scale ? part * ps_cur : part;
@@ -309,16 +310,218 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
             // clt_decode_bwd_acts -> clt_segment_sum
             gs_acc += mul_rounded(part, v_e + pe_cur * posf);
             gp_acc += mul_rounded(u_, posf);
-            if (lane == jj + u) my_u = u_;
+            if (lane == jj + u) my_u += u_;
           }
         }
       }
     }
     if constexpr (BWD) {
-      if (pos < end) bw.grad_acts[my_e] += my_u;  // every entry belongs to exactly one row: no conflicts
+      if (pos < end) bw.grad_acts[my_e] = my_u;  // every entry belongs to exactly one row: no conflicts
     }
   }
   flush_until(nrows);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-staged variant of the fused-optimizer row pass (same arithmetic, same order, bitwise the same results).
+// spt_dense_kernel keeps the optimizer state of one row ahead in registers; with the decoder backward fused it needs
+// 180 VGPRs (two waves per SIMD) and the parameter row at the row's FIRST entry.  Here one wave owns ONE row: it asks
+// for the row's parameter, exp_avg and exp_avg_sq chunks with LDS-DMA (global_load_lds_dwordx4, non-temporal: no
+// registers held while in flight), issues the segment loads and the gathers behind them and finds the row in LDS
+// afterwards.  ~100 VGPRs, four waves per SIMD; measured 5.5 TB/s without and 4.5 TB/s with the backward (the
+// register version: 5.1 / 3.7).  Workgroup = 2 waves, dynamic LDS = 2 * 3 * row bytes.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+__device__ __forceinline__ void rows_dma16(const void* src, uint32_t lds_dst) {
+  // LDS[lds_dst + 16 * lane] = *(16 bytes at src), lanes masked by EXEC do nothing.  Inline asm: hipcc does not count
+  // it (its own vmcnt waits only become more conservative); our reads of the staged rows wait for vmcnt(0).
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off nt\n\t"  // streamed once: keep the gathered dense rows in L2 / Infinity Cache
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_dst)
+      : "memory");
+}
+
+template <typename T, int CH, int U, bool BWD>
+__global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets, int64_t M, const float* __restrict__ vals,
+    const void* __restrict__ gate, int gate_dtype, const T* __restrict__ dense, int d, int k, T* __restrict__ out,
+    float* __restrict__ rowsum, const AdamRows ad, const BwdActs bw) {
+  constexpr int E = Chunk<T>::E;  // 16-byte chunks of the state rows and of the dense rows alike
+  extern __shared__ __attribute__((aligned(16))) char rows_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 2 + wave;
+  if (row >= M) return;
+  const int nchunks = d / E;
+  const int rowbytes = d * (int)sizeof(T);
+  char* my_lds = rows_lds + (size_t)wave * 3 * rowbytes;
+  // (wave-uniform, but hipcc cannot know: readfirstlane puts it in an SGPR for the m0 moves)
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void_ptr)my_lds);
+  const int my_off = lane < 2 ? offsets[row + lane] : 0;
+  const int64_t roff = row * (int64_t)d;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {  // [p, m, v][chunk], chunk-linear
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      const uint32_t dst = lds0 + (uint32_t)(c * 1024);
+      rows_dma16(out + roff + ch * E, dst);
+      rows_dma16(reinterpret_cast<const T*>(ad.m) + roff + ch * E, dst + rowbytes);
+      rows_dma16(reinterpret_cast<const T*>(ad.v) + roff + ch * E, dst + 2 * rowbytes);
+    }
+  }
+  const int beg = readlane_i(my_off, 0), end = readlane_i(my_off, 1);
+
+  float acc[CH][E];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+  float rs = 0.f, pe_r = 0.f, ps_r = 1.f, gp_acc = 0.f, gs_acc = 0.f;
+  if constexpr (BWD) {
+    if (bw.post_enc) pe_r = bw.post_enc[row];
+    if (bw.post_scale) ps_r = bw.post_scale[row];
+  }
+  auto lds_chunk = [&](int arr, int c, float (&f)[E]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(my_lds + arr * rowbytes + (lane + 64 * c) * 16);
+    Chunk<T>::expand(u, f);
+  };
+  float wrow[BWD ? CH : 1][E];
+  bool staged = false;  // wave-uniform
+
+  for (int s0 = beg; s0 < end; s0 += 64) {
+    int my_n = 0, my_e = 0;
+    float my_w = 0.f, my_v = 0.f, my_u = 0.f;
+    const int pos = s0 + lane;
+    if (pos < end) {
+      const int e = perm[pos];
+      my_e = e;
+      if constexpr (BWD) {
+        my_v = load_scalar(bw.v, bw.v_dtype, e);
+        my_u = bw.grad_acts[e];  // fetched with the entry: only a store is left at the end of the chunk
+      }
+      float w = vals[e];
+      if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
+      my_w = w;
+      my_n = e / k;
+    }
+    const int cnt = min(64, end - s0);
+    for (int jj = 0; jj < cnt; jj += U) {
+      uint4 raw[U][CH];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jl = min(jj + u, cnt - 1);
+        const int n = readlane_i(my_n, jl);
+        const char* grow = reinterpret_cast<const char*>(dense) + (size_t)n * (size_t)d * sizeof(T);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(grow + (size_t)ch * 16);
+        }
+      }
+      if constexpr (BWD) {
+        if (!staged) {  // the row's first entries: the parameter row (before its update) out of LDS
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          staged = true;
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+            if (lane + 64 * c < nchunks) lds_chunk(0, c, wrow[c]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (jj + u < cnt) {  // wave-uniform
+          const float w = readlane_f(my_w, jj + u);
+          rs += w;
+          float part = 0.f;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+              float x[E];
+              Chunk<T>::expand(raw[u][c], x);
+#pragma unroll
+              for (int e = 0; e < E; ++e) acc[c][e] = fmaf(w, x[e], acc[c][e]);
+              if constexpr (BWD) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) part = fmaf(x[e], wrow[c][e], part);
+              }
+            }
+          }
+          if constexpr (BWD) {
+            part = wave_sum_dpp(part);
+            const float v_e = readlane_f(my_v, jj + u);
+            const float posf = v_e > 0.f ? 1.f : 0.f;
+            const float u_ = bw.post_scale ? part * ps_r : part;
+            gs_acc += mul_rounded(part, v_e + pe_r * posf);
+            gp_acc += mul_rounded(u_, posf);
+            if (lane == jj + u) my_u += u_;
+          }
+        }
+      }
+    }
+    if constexpr (BWD) {
+      if (pos < end) bw.grad_acts[my_e] = my_u;  // every entry belongs to exactly one row: no conflicts
+    }
+  }
+
+  // ---- the row is complete: optimizer update out of LDS
+  if (!staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      float pf[E], mf[E], vf[E];
+      lds_chunk(0, c, pf);
+      lds_chunk(1, c, mf);
+      lds_chunk(2, c, vf);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float g = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+        adam_update(pf[e], mf[e], vf[e], g, ad.step_size, ad.b1, ad.b2, ad.inv_sqrt_bc2, ad.eps);
+      }
+      store_row_chunk<T, E>(out + roff + ch * E, pf);
+      store_row_chunk<T, E>(reinterpret_cast<T*>(ad.m) + roff + ch * E, mf);
+      store_row_chunk<T, E>(reinterpret_cast<T*>(ad.v) + roff + ch * E, vf);
+    }
+  }
+  if (lane == 0) {
+    if (rowsum) rowsum[row] = rs;
+    if constexpr (BWD) {
+      if (bw.g_post) bw.g_post[row] = gp_acc;
+      if (bw.g_scale) bw.g_scale[row] = gs_acc;
+    }
+  }
+}
+
+// The LDS-staged kernel serves rows of up to 10 KiB (2 waves * 3 arrays * row <= 64 KiB of LDS) and 8 chunks per lane.
+static inline bool rows_lds_ok(int d, size_t elem, int ch) {
+  static const bool off = getenv("CLT_ROWS_LDS") && atoi(getenv("CLT_ROWS_LDS")) == 0;  // A/B switch (tests, tuning)
+  return !off && ch <= 8 && 2 * 3 * (size_t)d * elem <= 65536;
+}
+
+template <typename T, bool BWD>
+static int launch_rows_lds(int ch, hipStream_t st, const int32_t* perm, const int32_t* offsets, int64_t M,
+                           const float* vals, const void* gate, int gate_dtype, const void* dense, int d, int k, void* out,
+                           float* rowsum, AdamRows ad, BwdActs bw) {
+  const dim3 grid((unsigned)((M + 1) / 2));
+  const size_t lds = 2 * 3 * (size_t)d * sizeof(T);
+#define LAUNCH(CH, U)                                                                                                 \
+  hipLaunchKernelGGL((rows_lds_kernel<T, CH, U, BWD>), grid, dim3(128), lds, st, perm, offsets, M, vals, gate,        \
+                     gate_dtype, (const T*)dense, d, k, (T*)out, rowsum, ad, bw)
+  switch (ch) {
+    case 1: LAUNCH(1, 8); break;
+    case 2: LAUNCH(2, 4); break;
+    case 4: LAUNCH(4, 4); break;
+    case 8: LAUNCH(8, 2); break;
+    default: return CLT_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH
+  return CLT_OK;
 }
 
 template <typename DT, typename OT, bool ADAM = false, bool BWD = false>
@@ -340,7 +543,12 @@ static int launch_spt(int ch, hipStream_t st, const int32_t* perm, const int32_t
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
     case 2:
-      if (ADAM) { LAUNCH(2, 4); }  // fewer gathers in flight, more waves: the state streams need the occupancy
+      if (ADAM && BWD) {
+        static const int tune_u = getenv("CLT_ROWS_U") ? atoi(getenv("CLT_ROWS_U")) : 4;  // TUNING ONLY
+        if (tune_u == 2) { LAUNCH(2, 2); }
+        else if (tune_u == 3) { LAUNCH(2, 3); }
+        else { LAUNCH(2, 4); }
+      } else if (ADAM) { LAUNCH(2, 4); }  // fewer gathers in flight, more waves: the state streams need the occupancy
       else { LAUNCH(2, 8); }
       break;
     case 4: LAUNCH(4, 4); break;
