@@ -64,6 +64,13 @@ class SimComm:
             parts = [p + r * self.m_local for r, p in enumerate(parts)]
         return torch.cat(parts, 1).contiguous()
 
+    def all_to_all_rows(self, t):
+        n = t.shape[0] // self.world
+        parts = [t[:n].roll(37 * r, 0) for r in range(self.world)]
+        if t.dtype == torch.int64:  # packed (value bits << 32 | global index) candidates of pretend rank r
+            parts = [p + r * self.m_local for r, p in enumerate(parts)]
+        return torch.cat(parts, 0)
+
     def reduce_scatter_rows(self, t):
         return t[: t.shape[0] // self.world].clone()
 
@@ -71,8 +78,16 @@ class SimComm:
         return t
 
 
-def algorithmic_work(name, N, d, M, k, es, P_total):
-    """Algorithmic flops / bytes per launch -> (amount, 'flop'|'byte')."""
+def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.0):
+    """Algorithmic flops / bytes per launch -> (amount, 'flop'|'byte').
+    N = tokens of the whole group, M = latents of this rank, k / world = entries a rank owns per token and source;
+    pairs_per_target = mean number of live sources per target launch ((L + 1) / 2 with cross_layer = L)."""
+    if name in ("clt_decode_fwd_multi", "clt_decode_bwd_acts_multi"):  # the pairs of one target: gathered rows + one row
+        return es * N * (pairs_per_target * k / world + 1) * d, "byte"
+    if name == "clt_decode_bwd_rows_adam":  # parameter / exp_avg / exp_avg_sq rows read + written, G rows gathered
+        return es * (6 * M * d + N * k / world * d), "byte"
+    if name == "clt_decode_bwd_rows":
+        return es * (2 * M * d + N * k / world * d), "byte"
     if name in ("clt_encoder_gemm_relu", "clt_encode_topk_fwd"):  # the fused call is priced as its GEMM alone
         return 2.0 * N * d * M, "flop"
     if name == "clt_topk_rows":
@@ -80,9 +95,9 @@ def algorithmic_work(name, N, d, M, k, es, P_total):
     if name in ("clt_decode_fwd", "clt_decode_bwd_acts"):
         return es * N * (k + 1) * d, "byte"
     if name == "clt_spt_dense":
-        return es * (M * d + N * k * d), "byte"
+        return es * (M * d + N * k / world * d), "byte"
     if name == "clt_spt_dense_adam":  # gathered rows + read/write of the parameter, exp_avg and exp_avg_sq rows
-        return es * (6 * M * d + N * k * d), "byte"
+        return es * (6 * M * d + N * k / world * d), "byte"
     if name == "clt_adam_step":
         return 7.0 * es * P_total, "byte"
     if name == "clt_fvu_fwd_bwd":
@@ -199,7 +214,7 @@ def main():
         kernels = {}
         dominant, dom_ms = None, -1.0
         for name, (cnt, ms) in prof.summary().items():
-            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_adam)
+            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_adam, world, (L + 1) / 2)
             ent = {"launches_per_step": cnt / args.steps, "mean_ms": round(ms, 4),
                    "ms_per_step": round(ms * cnt / args.steps, 3)}
             if amount is not None:
