@@ -302,25 +302,39 @@ class CLTEngine:
 
     # ---- one hook call (trainer.py:492-682)
     @torch.no_grad()
-    def layer_step(self, j: int, x_r: Tensor, y_r: Tensor, mask_r: Optional[Tensor], acc_steps: int = 1) -> Tensor:
+    def encode_part(self, j: int, x_r: Tensor, y_r: Tensor) -> dict:
+        """The encoder half of a hook call (sparse_coder.py:632-647, fused_encoder.py:293-372): normalise, all-gather
+        the inputs of the group, local GEMM + top-k, TP merge.  It depends on nothing the decoder / backward half of
+        EARLIER layers produces, so a caller may run it one layer ahead on a second stream (tp.TPTrainer does, to hide
+        the collectives of either half behind the kernels of the other)."""
         ops, comm = self.ops, self.comm
         lp = self.coders[j]
         cfg = lp.cfg
         cd = self._cd(lp)
         d, k = lp.d_in, cfg.k
-        Ml, lat0 = lp.m_local, lp.lat_begin
         if not cfg.transcode:
             x_r = y_r
-        # ---------------- encode (sparse_coder.py:632-647, fused_encoder.py:293-372)
         xn_r = x_r.float() * (d**0.5 / lp.in_norm) if cfg.normalize_io else x_r
         x_enc_r = xn_r if cfg.transcode else xn_r.float() - lp.b_decs[0]
         x_enc = comm.all_gather_rows(x_enc_r.to(cd))
         v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, k, out_dtype=cd)
         if comm.world > 1:
-            v, idx = self._merge_candidates(v, idx + lat0, k)
+            v, idx = self._merge_candidates(v, idx + lp.lat_begin, k)
+        return dict(xn_r=self._keep_input(j, xn_r.to(cd)), x_enc=x_enc, v=v, idx=idx)
+
+    @torch.no_grad()
+    def layer_step(self, j: int, x_r: Tensor, y_r: Tensor, mask_r: Optional[Tensor], acc_steps: int = 1,
+                   enc: Optional[dict] = None) -> Tensor:
+        ops, comm = self.ops, self.comm
+        lp = self.coders[j]
+        cfg = lp.cfg
+        cd = self._cd(lp)
+        d, k = lp.d_in, cfg.k
+        if enc is None:
+            enc = self.encode_part(j, x_r, y_r)
+        x_enc, v, idx = enc["x_enc"], enc["v"], enc["idx"]
         N = x_enc.shape[0]
-        me = _Live(j, self._keep_input(j, xn_r.to(cd)), x_enc, v, idx,
-                   torch.zeros(N, k, dtype=torch.float32, device=v.device))
+        me = _Live(j, enc["xn_r"], x_enc, v, idx, torch.zeros(N, k, dtype=torch.float32, device=v.device))
         self.live.append(me)
         div = max(1, len(self.live) - 1) if cfg.divide_cross_layer else 1  # runner.py:46-49
 

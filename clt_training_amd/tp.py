@@ -75,6 +75,7 @@ class TPTrainer:
         self.did_fire = {h: f[:-1] for h, f in self._did_fire.items()}
         self.num_tokens_in_step = 0
         self.last_fvu = {}
+        self._enc_stream = None
 
     @torch.no_grad()
     def step(self, batch: dict):
@@ -83,7 +84,29 @@ class TPTrainer:
         eng.reset()
         mask = batch.get("loss_mask")
         n_tok = 0
-        for j, name in enumerate(cfg.hookpoints):
+        # Two streams under tp > 1: the encoder half of layer j + 1 (input all-gather, GEMM + top-k, candidate
+        # exchange) is enqueued on a side stream before the decoder / backward half of layer j on the main stream, so
+        # the collectives of either half run behind the kernels of the other.  Step 0 (data-dependent init) is serial.
+        names = cfg.hookpoints
+        overlap = (self.comm.world > 1 and self.device.type == "cuda" and self.global_step > 0
+                   and not os.environ.get("CLT_NO_OVERLAP"))
+        pending = {}
+        if overlap:
+            main = torch.cuda.current_stream(self.device)
+            if self._enc_stream is None:
+                self._enc_stream = torch.cuda.Stream(self.device)
+            self._enc_stream.wait_stream(main)  # last step's parameter updates; this step's batch
+
+            def launch_encode(jj):
+                xx, yy = batch[names[jj]]
+                with torch.cuda.stream(self._enc_stream):
+                    e = eng.encode_part(jj, xx, yy)
+                    ev = torch.cuda.Event()
+                    ev.record(self._enc_stream)
+                pending[jj] = (e, ev)
+
+            launch_encode(0)
+        for j, name in enumerate(names):
             x, y = batch[name]
             sae = self.saes[name]
             n_tok = x.shape[0] * self.comm.world
@@ -92,7 +115,15 @@ class TPTrainer:
             if sae.cfg.normalize_decoder and not cfg.sae.transcode:  # trainer.py:595-596 (row-wise: shard-local)
                 W = sae.W_decs[0]
                 W.data /= W.data.norm(dim=1, keepdim=True) + torch.finfo(W.dtype).eps
-            self.last_fvu[name] = eng.layer_step(j, x, y, mask, acc_steps)
+            enc = None
+            if overlap:
+                if j + 1 < len(names):
+                    launch_encode(j + 1)
+                enc, ev = pending.pop(j)
+                main.wait_event(ev)
+                for t in enc.values():
+                    t.record_stream(main)  # allocated on the side stream, consumed (and released) on this one
+            self.last_fvu[name] = eng.layer_step(j, x, y, mask, acc_steps, enc=enc)
             # fired-latent bookkeeping on this rank's latent range (trainer.py:622-628)
             loc = eng.last_idx[j].flatten() - sae.lat_begin
             if self.comm.world > 1:
