@@ -57,7 +57,8 @@ extern "C" int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offs
                                         const void* v, int v_dtype, const float* post_enc, const float* post_scale,
                                         const void* G, int g_dtype, int d, int k, void* W, void* exp_avg,
                                         void* exp_avg_sq, int w_dtype, float* grad_acts, float* g_post, float* g_scale,
-                                        float lr, float b1, float b2, float eps, int step, clt_stream_t stream) {
+                                        float lr, float b1, float b2, float eps, int step, int64_t n_entries,
+                                        void* workspace, size_t workspace_bytes, clt_stream_t stream) {
   int ch;
   int rc = check_rows_args("clt_decode_bwd_rows_adam", perm, offsets, M, acts, v, v_dtype, post_scale, G, g_dtype, d, k,
                            W, w_dtype, grad_acts, g_scale, &ch);
@@ -69,9 +70,9 @@ extern "C" int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offs
   hipStream_t st = (hipStream_t)stream;
   const bool lds_ok = rows_lds_ok(d, dtype_size(w_dtype), ch);
   if (lds_ok && g_dtype == CLT_BF16)
-    rc = launch_rows_lds<bf16_t, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw);
+    rc = launch_rows_lds<bf16_t, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw, n_entries, workspace, workspace_bytes);
   else if (lds_ok)
-    rc = launch_rows_lds<float, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw);
+    rc = launch_rows_lds<float, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw, n_entries, workspace, workspace_bytes);
   else if (g_dtype == CLT_BF16)
     rc = launch_spt<bf16_t, bf16_t, true, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, W, nullptr, ad, bw);
   else

@@ -20,8 +20,10 @@ namespace clt {
 
 // key = latent - lat_begin, or the sentinel M for entries of other shards (sorted behind every real segment)
 __global__ void seg_prepare_kernel(const int64_t* __restrict__ idx, int32_t* __restrict__ keys,
-                                   int32_t* __restrict__ ids, int64_t n, int64_t M, int64_t lat_begin) {
+                                   int32_t* __restrict__ ids, int64_t n, int64_t M, int64_t lat_begin,
+                                   int32_t* __restrict__ offsets) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) offsets[M + 1] = 0;  // "some segment is long" flag, raised by seg_offsets_kernel
   if (i < n) {
     const int64_t r = idx[i] - lat_begin;
     keys[i] = (r >= 0 && r < M) ? (int32_t)r : (int32_t)M;
@@ -29,11 +31,13 @@ __global__ void seg_prepare_kernel(const int64_t* __restrict__ idx, int32_t* __r
   }
 }
 
-// offsets[r] = first position p with sorted_keys[p] >= r;  offsets[M] = n.
+// offsets[r] = first position p with sorted_keys[p] >= r;  offsets[M] = number of owned entries;
+// offsets[M + 1] = 1 if some segment holds more than ROWS_LT entries (the same key ROWS_LT positions apart).
 __global__ void seg_offsets_kernel(const int32_t* __restrict__ sorted_keys, int32_t* __restrict__ offsets,
                                    int64_t n, int64_t M) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
+  if (i + ROWS_LT < n && sorted_keys[i] < M && sorted_keys[i] == sorted_keys[i + ROWS_LT]) offsets[M + 1] = 1;
   int64_t lo = (i == 0) ? 0 : (int64_t)sorted_keys[i - 1] + 1;
   int64_t hi = (i == n) ? M : (int64_t)sorted_keys[i];
   if (hi > M) hi = M;  // defensive: out-of-range keys never index offsets
@@ -99,7 +103,7 @@ extern "C" int clt_segments_build(const int64_t* idx, int64_t n, int64_t M, int6
   void* temp = ws + 3 * a;
   size_t temp_bytes = sort_temp_bytes(n, M);
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(seg_prepare_kernel, dim3(blocks), dim3(256), 0, st, idx, keys_in, ids_in, n, M, lat_begin);
+  hipLaunchKernelGGL(seg_prepare_kernel, dim3(blocks), dim3(256), 0, st, idx, keys_in, ids_in, n, M, lat_begin, offsets);
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int32_t*)keys_in, keys_out,
                                            (const int32_t*)ids_in, perm, (size_t)n, 0, key_bits(M), st, false);
   if (e != hipSuccess) {
@@ -144,10 +148,15 @@ extern "C" int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_
   return CLT_OK;
 }
 
+extern "C" size_t clt_rows_workspace_bytes(int64_t n_entries, int d) {
+  return n_entries > 0 && d > 0 ? rows_long_workspace_bytes(n_entries, d) : 256;
+}
+
 extern "C" int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, int64_t M, const float* vals,
                                   const void* vals_gate, int gate_dtype, const void* dense, int dense_dtype, int d, int k,
                                   void* p, void* m, void* v, int p_dtype, float* rowsum, float lr, float b1, float b2,
-                                  float eps, int step, clt_stream_t stream) {
+                                  float eps, int step, int64_t n_entries, void* workspace, size_t workspace_bytes,
+                                  clt_stream_t stream) {
   CLT_CHECK_ARG(perm && offsets && vals && dense && p && m && v, "clt_spt_dense_adam: null pointer");
   CLT_CHECK_ARG(M > 0 && M < (1ll << 31) && d > 0 && k > 0 && step >= 1, "clt_spt_dense_adam: bad sizes");
   CLT_CHECK_ARG(valid_dtype(dense_dtype) && valid_dtype(p_dtype) && (!vals_gate || valid_dtype(gate_dtype)),
@@ -165,9 +174,9 @@ extern "C" int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, i
   int rc;
   const bool lds_ok = dense_dtype == p_dtype && rows_lds_ok(d, dtype_size(p_dtype), ch);
   if (lds_ok && p_dtype == CLT_BF16)
-    rc = launch_rows_lds<bf16_t, false>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad, BwdActs());
+    rc = launch_rows_lds<bf16_t, false>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad, BwdActs(), n_entries, workspace, workspace_bytes);
   else if (lds_ok)
-    rc = launch_rows_lds<float, false>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad, BwdActs());
+    rc = launch_rows_lds<float, false>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad, BwdActs(), n_entries, workspace, workspace_bytes);
   else if (dense_dtype == CLT_BF16 && p_dtype == CLT_BF16)
     rc = launch_spt<bf16_t, bf16_t, true>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, p, rowsum, ad);
   else if (dense_dtype == CLT_BF16 && p_dtype == CLT_F32)

@@ -75,6 +75,20 @@ struct BwdActs {
   const void* W;            // [M, d] table rows when they are not the Adam parameter (plain gradient output)
 };
 
+template <int E>
+__device__ __forceinline__ void store_elems_f32(float* p, const float (&a)[E]) {
+#pragma unroll
+  for (int q = 0; q < E; q += 4) *reinterpret_cast<float4*>(p + q) = make_float4(a[q], a[q + 1], a[q + 2], a[q + 3]);
+}
+template <int E>
+__device__ __forceinline__ void load_elems_f32(const float* p, float (&a)[E]) {
+#pragma unroll
+  for (int q = 0; q < E; q += 4) {
+    const float4 f = *reinterpret_cast<const float4*>(p + q);
+    a[q] = f.x; a[q + 1] = f.y; a[q + 2] = f.z; a[q + 3] = f.w;
+  }
+}
+
 template <typename PT, int E>
 __device__ __forceinline__ void load_row_chunk(const PT* p, float (&a)[E]) {
   if constexpr (sizeof(PT) == 2 && E == 8) {
@@ -347,11 +361,160 @@ __device__ __forceinline__ void rows_dma16(const void* src, uint32_t lds_dst) {
       : "memory");
 }
 
+// ---- long rows.  A latent that fires on most tokens owns a segment of thousands of entries; one wave walking it
+// alone would outlast the rest of the launch (the reference balances such rows by processing embeddings in
+// count-descending order, xformers.py:195,214-230, and sums with atomics).  Here the segment array is cut into blocks
+// of ROWS_LT positions; a helper launch lets one wave per block pre-reduce the part of every LONG row (more than
+// ROWS_LT entries) that falls into its block -- at most two such rows touch a block: one that began before it
+// (slot 0) and one that begins inside it (slot 1) -- into an fp32 partial row plus three partial scalars, and (BWD)
+// finishes the per-entry work of those entries.  The row pass then adds a long row's partials in block order instead
+// of gathering: deterministic, atomic-free, and no wave handles more than ROWS_LT entries.
+constexpr int ROWS_LT = 512;
+
+struct LongRows {
+  float* partial;  // [nblocks][2][d + 4] fp32 (row, then rs, gp, gs, pad); null = feature off
+  int stride;      // d + 4
+};
+
+static inline size_t rows_long_workspace_bytes(int64_t n_entries, int d) {
+  const int64_t nb = (n_entries + ROWS_LT - 1) / ROWS_LT;
+  return (size_t)nb * 2 * (size_t)(d + 4) * sizeof(float) + 256;
+}
+
+// first row r with offsets[r + 1] > pos (the row that holds segment position pos), rows are [0, M)
+__device__ __forceinline__ int row_of_position(const int32_t* __restrict__ offsets, int64_t M, int pos) {
+  int lo = 0, hi = (int)M - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (offsets[mid + 1] > pos) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo;
+}
+
+template <typename T, int CH, int U, bool BWD>
+__global__ __launch_bounds__(64) void rows_long_kernel(const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ offsets, int64_t M,
+                                                       const float* __restrict__ vals, const void* __restrict__ gate,
+                                                       int gate_dtype, const T* __restrict__ dense, int d, int k,
+                                                       const T* __restrict__ W, const BwdActs bw, const LongRows lr) {
+  constexpr int E = Chunk<T>::E;
+  const int lane = threadIdx.x;
+  if (offsets[M + 1] == 0) return;  // clt_segments_build found no long segment: nothing to pre-reduce
+  const int n_owned = offsets[M];
+  const int p0 = (int)blockIdx.x * ROWS_LT;
+  if (p0 >= n_owned) return;
+  const int p1 = min(p0 + ROWS_LT, n_owned);
+  const int nchunks = d / E;
+  const int row_a = row_of_position(offsets, M, p0), row_b = row_of_position(offsets, M, p1 - 1);
+  for (int which = 0; which < 2; ++which) {
+    const int row = which == 0 ? row_a : row_b;
+    if (which == 1 && row_b == row_a) break;
+    const int rbeg = offsets[row], rend = offsets[row + 1];
+    if (rend - rbeg <= ROWS_LT) continue;  // an ordinary row: the row pass gathers it
+    const int slot = rbeg < p0 ? 0 : 1;
+    const int beg = max(p0, rbeg), end = min(p1, rend);
+    float acc[CH][E];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+    float rs = 0.f, gp_acc = 0.f, gs_acc = 0.f, pe_r = 0.f, ps_r = 1.f;
+    float wrow[BWD ? CH : 1][E];
+    if constexpr (BWD) {
+      if (bw.post_enc) pe_r = bw.post_enc[row];
+      if (bw.post_scale) ps_r = bw.post_scale[row];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks) load_row_chunk<T, E>(W + (int64_t)row * d + ch * E, wrow[c]);
+      }
+    }
+    for (int s0 = beg; s0 < end; s0 += 64) {
+      int my_n = 0, my_e = 0;
+      float my_w = 0.f, my_v = 0.f, my_u = 0.f;
+      const int pos = s0 + lane;
+      if (pos < end) {
+        const int e = perm[pos];
+        my_e = e;
+        if constexpr (BWD) {
+          my_v = load_scalar(bw.v, bw.v_dtype, e);
+          my_u = bw.grad_acts[e];
+        }
+        float w = vals[e];
+        if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
+        my_w = w;
+        my_n = e / k;
+      }
+      const int cnt = min(64, end - s0);
+      for (int jj = 0; jj < cnt; jj += U) {
+        uint4 raw[U][CH];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int jl = min(jj + u, cnt - 1);
+          const int n = readlane_i(my_n, jl);
+          const char* grow = reinterpret_cast<const char*>(dense) + (size_t)n * (size_t)d * sizeof(T);
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(grow + (size_t)ch * 16);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (jj + u < cnt) {  // wave-uniform
+            const float w = readlane_f(my_w, jj + u);
+            rs += w;
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              const int ch = lane + 64 * c;
+              if (ch < nchunks) {
+                float x[E];
+                Chunk<T>::expand(raw[u][c], x);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[c][e] = fmaf(w, x[e], acc[c][e]);
+                if constexpr (BWD) {
+#pragma unroll
+                  for (int e = 0; e < E; ++e) part = fmaf(x[e], wrow[c][e], part);
+                }
+              }
+            }
+            if constexpr (BWD) {
+              part = wave_sum_dpp(part);
+              const float v_e = readlane_f(my_v, jj + u);
+              const float posf = v_e > 0.f ? 1.f : 0.f;
+              const float u_ = bw.post_scale ? part * ps_r : part;
+              gs_acc += mul_rounded(part, v_e + pe_r * posf);
+              gp_acc += mul_rounded(u_, posf);
+              if (lane == jj + u) my_u += u_;
+            }
+          }
+        }
+      }
+      if constexpr (BWD) {
+        if (pos < end) bw.grad_acts[my_e] = my_u;
+      }
+    }
+    float* prow = lr.partial + ((size_t)blockIdx.x * 2 + slot) * lr.stride;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) store_elems_f32<E>(prow + ch * E, acc[c]);
+    }
+    if (lane == 0) {
+      prow[d] = rs;
+      prow[d + 1] = gp_acc;
+      prow[d + 2] = gs_acc;
+    }
+  }
+}
+
 template <typename T, int CH, int U, bool BWD>
 __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds_kernel(
     const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets, int64_t M, const float* __restrict__ vals,
     const void* __restrict__ gate, int gate_dtype, const T* __restrict__ dense, int d, int k, T* __restrict__ out,
-    float* __restrict__ rowsum, const AdamRows ad, const BwdActs bw) {
+    float* __restrict__ rowsum, const AdamRows ad, const BwdActs bw, const LongRows lr) {
   constexpr int E = Chunk<T>::E;  // 16-byte chunks of the state rows and of the dense rows alike
   extern __shared__ __attribute__((aligned(16))) char rows_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -392,8 +555,27 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds
   };
   float wrow[BWD ? CH : 1][E];
   bool staged = false;  // wave-uniform
+  const bool is_long = lr.partial != nullptr && end - beg > ROWS_LT;  // pre-reduced by rows_long_kernel
+  if (is_long) {
+    for (int b = beg / ROWS_LT; b <= (end - 1) / ROWS_LT; ++b) {  // block order: fixed summation order
+      const float* prow = lr.partial + ((size_t)b * 2 + (beg < b * ROWS_LT ? 0 : 1)) * lr.stride;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks) {
+          float x[E];
+          load_elems_f32<E>(prow + ch * E, x);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[c][e] += x[e];
+        }
+      }
+      rs += prow[d];
+      gp_acc += prow[d + 1];
+      gs_acc += prow[d + 2];
+    }
+  }
 
-  for (int s0 = beg; s0 < end; s0 += 64) {
+  for (int s0 = beg; s0 < (is_long ? beg : end); s0 += 64) {
     int my_n = 0, my_e = 0;
     float my_w = 0.f, my_v = 0.f, my_u = 0.f;
     const int pos = s0 + lane;
@@ -507,12 +689,22 @@ static inline bool rows_lds_ok(int d, size_t elem, int ch) {
 template <typename T, bool BWD>
 static int launch_rows_lds(int ch, hipStream_t st, const int32_t* perm, const int32_t* offsets, int64_t M,
                            const float* vals, const void* gate, int gate_dtype, const void* dense, int d, int k, void* out,
-                           float* rowsum, AdamRows ad, BwdActs bw) {
+                           float* rowsum, AdamRows ad, BwdActs bw, int64_t n_entries, void* workspace,
+                           size_t workspace_bytes) {
   const dim3 grid((unsigned)((M + 1) / 2));
   const size_t lds = 2 * 3 * (size_t)d * sizeof(T);
+  LongRows lr = {nullptr, d + 4};
+  const bool longs = workspace != nullptr && n_entries > ROWS_LT && workspace_bytes >= rows_long_workspace_bytes(n_entries, d);
+  const dim3 lgrid((unsigned)((n_entries + ROWS_LT - 1) / ROWS_LT));
+  if (longs) lr.partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
 #define LAUNCH(CH, U)                                                                                                 \
-  hipLaunchKernelGGL((rows_lds_kernel<T, CH, U, BWD>), grid, dim3(128), lds, st, perm, offsets, M, vals, gate,        \
-                     gate_dtype, (const T*)dense, d, k, (T*)out, rowsum, ad, bw)
+  do {                                                                                                                \
+    if (longs)                                                                                                        \
+      hipLaunchKernelGGL((rows_long_kernel<T, CH, U, BWD>), lgrid, dim3(64), 0, st, perm, offsets, M, vals, gate,     \
+                         gate_dtype, (const T*)dense, d, k, (const T*)out, bw, lr);                                   \
+    hipLaunchKernelGGL((rows_lds_kernel<T, CH, U, BWD>), grid, dim3(128), lds, st, perm, offsets, M, vals, gate,      \
+                       gate_dtype, (const T*)dense, d, k, (T*)out, rowsum, ad, bw, lr);                               \
+  } while (0)
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
     case 2: LAUNCH(2, 4); break;

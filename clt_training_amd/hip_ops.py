@@ -276,11 +276,11 @@ def segments_build(idx: Tensor, M: int, lat_begin: int = 0) -> Segments:
     n = idx.numel()
     lib = _lib.load()
     perm = torch.empty(n, dtype=torch.int32, device=idx.device)
-    offsets = torch.empty(M + 1, dtype=torch.int32, device=idx.device)
+    offsets = torch.empty(M + 2, dtype=torch.int32, device=idx.device)  # [M + 1] bounds + the long-segment flag
     nbytes = lib.clt_segments_workspace_bytes(n, M)
     ws = workspace(idx.device, nbytes, "seg")
     _call("clt_segments_build", _ptr(idx), n, M, lat_begin, _ptr(perm), _ptr(offsets), _ptr(ws), ws.numel(), _stream(idx))
-    return Segments(perm, offsets, M, idx.shape[-1])
+    return Segments(perm, offsets[:M + 1], M, idx.shape[-1])  # (the kernels read the flag behind the view)
 
 
 def spt_dense(seg: Segments, vals: Tensor, dense: Tensor, *, gate: Optional[Tensor] = None, out_dtype=None,
@@ -309,9 +309,12 @@ def spt_dense_adam(seg: Segments, vals: Tensor, dense: Tensor, p: Tensor, m: Ten
     assert m.dtype == p.dtype and v.dtype == p.dtype and m.shape == p.shape and v.shape == p.shape
     rowsum = torch.empty(seg.M, dtype=torch.float32, device=dense.device) if want_rowsum else None
     gate = None if gate is None else _c(gate)
+    n = seg.perm.numel()
+    ws = workspace(dense.device, _lib.load().clt_rows_workspace_bytes(n, d), "rows")  # long-row partials
     _call("clt_spt_dense_adam", _ptr(seg.perm), _ptr(seg.offsets), seg.M, _ptr(vals), _ptr(gate),
           _dt(gate) if gate is not None else 0, _ptr(dense), _dt(dense), d, seg.k, _ptr(p), _ptr(m), _ptr(v), _dt(p),
-          _ptr(rowsum), float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), _stream(dense))
+          _ptr(rowsum), float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), n, _ptr(ws), ws.numel(),
+          _stream(dense))
     return rowsum
 
 
@@ -341,9 +344,11 @@ def decode_bwd_rows(seg: Segments, acts: Tensor, v: Tensor, W: Tensor, G: Tensor
     m_, v_ = adam["m"], adam["v"]
     assert m_.dtype == W.dtype and v_.dtype == W.dtype and m_.shape == W.shape and v_.shape == W.shape
     assert m_.is_contiguous() and v_.is_contiguous()
+    n = seg.perm.numel()
+    ws = workspace(W.device, _lib.load().clt_rows_workspace_bytes(n, d), "rows")  # long-row partials
     _call("clt_decode_bwd_rows_adam", *head, _ptr(W), _ptr(m_), _ptr(v_), _dt(W), _ptr(grad_acts), _ptr(g_post),
           _ptr(g_scale), float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]), float(adam["eps"]),
-          int(adam["step"]), _stream(W))
+          int(adam["step"]), n, _ptr(ws), ws.numel(), _stream(W))
     return None, g_post, g_scale
 
 

@@ -142,7 +142,9 @@ int clt_decode_bwd_acts_multi(const clt_decode_source* h_sources, int n_sources,
  * Stable sort of the N*k (token, slot) entries by latent: replaces the COO sort of
  * kernels.py:42-51 and the count/cumsum/reverse-map kernels of xformers.py:93-122,
  * deterministically (entries of one latent stay in ascending entry id).
- *   perm [N*k] int32: entry ids (n*k + j) grouped by latent; offsets [M+1] int32.
+ *   perm [N*k] int32: entry ids (n*k + j) grouped by latent; offsets [M+2] int32: offsets[r] .. offsets[r+1] is the
+ *   segment of local row r, offsets[M] = number of entries this shard owns, offsets[M+1] = 1 if some segment
+ *   holds more than 512 entries (read by the long-row helper of clt_spt_dense_adam / clt_decode_bwd_rows_adam).
  * Sharded: only entries with idx in [lat_begin, lat_begin + M) form segments (local row = idx - lat_begin);
  * the others are sorted behind offsets[M].                                            */
 size_t clt_segments_workspace_bytes(int64_t n_entries, int64_t M);
@@ -169,11 +171,18 @@ int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_t M, const 
  *   m, v, p updated exactly as clt_adam_step does (lr is the group's current lr; step is 1-based).
  * p, m, v [M,d] `p_dtype`, updated in place; the gradient row never reaches memory (4 of the 16 bytes per
  * parameter that grad write + Adam move).  rowsum as in clt_spt_dense.  Bitwise equal to clt_spt_dense followed
- * by clt_adam_step.                                                                                            */
+ * by clt_adam_step.
+ * Long rows: a latent active on most tokens owns thousands of entries (the reference balances such embeddings by a
+ * count-descending schedule and atomics, xformers.py:195,214-230).  With a `workspace` of
+ * clt_rows_workspace_bytes(n_entries, d) bytes (n_entries = length of perm = N*k) every segment of more than 512
+ * entries is pre-reduced in blocks of 512 by a helper launch and its partial rows are added in block order:
+ * deterministic, atomic-free; only the fp32 summation order of THOSE rows differs from clt_spt_dense.  workspace
+ * NULL: every row is walked by one wave.                                                                        */
+size_t clt_rows_workspace_bytes(int64_t n_entries, int d);
 int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, int64_t M, const float* vals, const void* vals_gate,
                        int gate_dtype, const void* dense, int dense_dtype, int d, int k, void* p, void* m, void* v,
                        int p_dtype, float* rowsum, float lr, float b1, float b2, float eps, int step,
-                       clt_stream_t stream);
+                       int64_t n_entries, void* workspace, size_t workspace_bytes, clt_stream_t stream);
 
 /* Decoder backward of one (source, target) pair as ONE row pass: the weight gradient of clt_spt_dense (xformers.py:
  * 125-166), the gradient wrt the bag weights of clt_decode_bwd_acts (xformers.py:167-171) and the per-latent sums
@@ -186,7 +195,8 @@ int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, int64_t M, c
  * touched: zero it before the source's first target); g_post / g_scale [M] fp32 or NULL are overwritten.
  * clt_decode_bwd_rows writes the gradient to grad_W [M,d] (`w_dtype`); clt_decode_bwd_rows_adam consumes it in the
  * Adam update of (W, exp_avg, exp_avg_sq) exactly as clt_spt_dense_adam does, with ga taken against the row
- * BEFORE the update.  Results are bitwise those of the three separate entry points.                        */
+ * BEFORE the update.  Results are bitwise those of the three separate entry points (long rows, when a workspace
+ * is given to the _adam form: see clt_spt_dense_adam).                                                     */
 int clt_decode_bwd_rows(const int32_t* perm, const int32_t* offsets, int64_t M, const float* acts, const void* v,
                         int v_dtype, const float* post_enc, const float* post_scale, const void* G, int g_dtype, int d,
                         int k, const void* W, int w_dtype, void* grad_W, float* grad_acts, float* g_post,
@@ -195,7 +205,7 @@ int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offsets, int64_
                              int v_dtype, const float* post_enc, const float* post_scale, const void* G, int g_dtype,
                              int d, int k, void* W, void* exp_avg, void* exp_avg_sq, int w_dtype, float* grad_acts,
                              float* g_post, float* g_scale, float lr, float b1, float b2, float eps, int step,
-                             clt_stream_t stream);
+                             int64_t n_entries, void* workspace, size_t workspace_bytes, clt_stream_t stream);
 
 /* Per-latent sums of up to two per-entry arrays (post_enc / post_enc_scale grads: the
  * scatter-adds autograd generates for sparse_coder.py:136-140):
