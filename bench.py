@@ -232,9 +232,9 @@ def main():
             # HBM bytes per launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs at these
             # layer shapes; counters cannot be read from inside this process)
             traffic = None
-            pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
-            if pmc.exists() and world == 1 and (N, d, M, k, es) == (8192, 768, 98304, 32, 2):
-                traffic = json.loads(pmc.read_text())["kernels"].get(dominant, {}).get("hbm_bytes")
+            pmcs = sorted((ROOT / "profiles").glob("r*_pmc_traffic*.json"))  # the newest pass (tools/pmc_traffic.py)
+            if pmcs and world == 1 and (N, d, M, k, es) == (8192, 768, 98304, 32, 2):
+                traffic = json.loads(pmcs[-1].read_text())["kernels"].get(dominant, {}).get("hbm_bytes")
             roofline = {"kernel": dominant, "bound": e["bound"], "achieved": e["achieved"],
                         "peak": 2500.0 if e["bound"] == "mfma" else 8000.0, "unit": e["unit"], "frac": e["frac"],
                         "traffic": traffic}

@@ -16,11 +16,14 @@ ap.add_argument("--M", type=int, default=98304)
 ap.add_argument("--k", type=int, default=32)
 ap.add_argument("--T", type=int, default=8)
 ap.add_argument("--tp", type=int, default=1, help="own 1/tp of the latents of N*tp tokens")
+ap.add_argument("--dense-latents", type=int, default=0, help="this many latents are active on EVERY token (long segments)")
 a = ap.parse_args()
 N, d, M, k, T = a.N * a.tp, a.d, a.M // a.tp, a.k, a.T
 dev = "cuda"
 torch.manual_seed(0)
 idx = torch.stack([torch.randperm(a.M, device=dev)[:k] for _ in range(N)]) if N <= 8192 else torch.randint(0, a.M, (N, k), device=dev)
+for j in range(a.dense_latents):
+    idx[:, j] = 100 + j
 v = torch.rand(N, k, device=dev).bfloat16()
 G = torch.randn(N, d, device=dev).bfloat16()
 acts = torch.rand(N, k, device=dev)

@@ -60,6 +60,10 @@ def main():
         w_med = statistics.median([v for v in wv if v > 0] or [0.0])
         kernels[tag] = {"launches": len(fv), "FETCH_SIZE_KiB": f_med, "WRITE_SIZE_KiB": w_med,
                         "hbm_bytes": int(1024 * (2 * f_med + w_med))}
+    # the fused encoder call = sample GEMM + sample top-k + filter GEMM + merge (its gated fallback launches fetch nothing)
+    stages = [k for k in kernels if k.startswith("gemm_fast_kernel") or k in ("clt_topk_rows(sample)", "fused_select_kernel")]
+    if stages:
+        kernels["clt_encode_topk_fwd"] = {"stages": stages, "hbm_bytes": sum(kernels[k]["hbm_bytes"] for k in stages)}
     doc = {"command": "rocprofv3 --pmc FETCH_SIZE (then, in a second run, --pmc WRITE_SIZE) --output-format csv -- python3 "
                       "bench.py --steps 1 --warmup 1 --layers 2 --no-cpu-baseline; tools/pmc_traffic.py",
            "note": "per-launch medians at BASELINE configs[1] layer shapes (N=8192, d=768, M=98304, k=32, bf16); counters are "
@@ -69,7 +73,7 @@ def main():
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     for k, v in kernels.items():
-        print(f"{k:50s} {v['launches']:4d} launches  {v['hbm_bytes'] / 1e6:10.1f} MB")
+        print(f"{k:50s} {v.get('launches', 0):4d} launches  {v['hbm_bytes'] / 1e6:10.1f} MB")
 
 
 if __name__ == "__main__":
