@@ -344,7 +344,8 @@ class CLTEngine:
         # so sum_i x_i @ W_skip_i^T = X_live @ cat_i(W_skip_i^T), with 1/div folded into the other sources' blocks.
         scale = [1.0 if st is me else 1.0 / div for st in self.live]
         Wt = [self.coders[st.layer].W_decs[st.slot] for st in self.live]
-        multi = hasattr(ops, "decode_fwd_multi") and all(w.shape == Wt[0].shape and w.dtype == Wt[0].dtype for w in Wt)
+        multi = (hasattr(ops, "decode_fwd_multi") and all(w.shape == Wt[0].shape and w.dtype == Wt[0].dtype for w in Wt)
+                 and not os.environ.get("CLT_NO_MULTI"))  # (the switch is for A/B tests and timing only)
         if multi:  # every live source in ONE launch: fp32 sum over all sources, one rounding, one output write
             srcs = []
             for st, sc_ in zip(self.live, scale):

@@ -196,3 +196,57 @@ def test_fused_row_adam_equals_grad_then_adam(monkeypatch):
             assert float(a[h]) == float(b[h])
     moved = [n for n in pa if "W_decs" in n or n.endswith("W_enc")]
     assert moved
+
+
+@pytest.mark.parametrize("shape", ["c3_d2048_k64_clt", "c4_d4096_k192_sae"])
+def test_engine_fast_path_equals_separate_kernels_at_config_widths(monkeypatch, shape):
+    """BASELINE configs[2] / configs[3] widths (Llama-3.2-1B CLT: d=2048, k=64; Llama-3-8B SAE: d=4096, k=192, unit-norm
+    decoder) through the engine's fast path (one-launch fan-out, row-pass decoder backward, fused Adam where allowed)
+    against the same steps on the single-pair kernels (CLT_NO_MULTI / CLT_NO_ROWS_PASS / CLT_NO_FUSED_ADAM): bf16
+    tolerance of BASELINE.json (the one-launch fan-out rounds the sum over sources once instead of once per source)."""
+    from clt_training_amd import SparseCoderConfig, TrainConfig
+    from clt_training_amd.tp import TPTrainer
+
+    if shape.startswith("c3"):
+        L, d, N, k, M, kw = 3, 2048, 192, 64, 8192, dict(transcode=True, skip_connection=True, post_encoder_scale=True)
+    else:
+        L, d, N, k, M, kw = 1, 4096, 128, 192, 8192, dict(transcode=False, normalize_decoder=True)
+    hooks = [f"h.{i}" for i in range(L)]
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for s in range(2):
+        b = {}
+        for h in hooks:
+            x = torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)
+            b[h] = (x.bfloat16().to(DEV), (0.5 * x + 0.5 * torch.randn(N, d, generator=g)).bfloat16().to(DEV))
+        b["loss_mask"] = (torch.rand(N, generator=g) > 0.1).to(DEV)
+        batches.append(b)
+
+    def run(fast):
+        for name in ("CLT_NO_MULTI", "CLT_NO_ROWS_PASS", "CLT_NO_FUSED_ADAM"):
+            if fast:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, "1")
+        torch.manual_seed(0)
+        cfg = TrainConfig(sae=SparseCoderConfig(dtype="bfloat16", num_latents=M, k=k, **kw), hookpoints=list(hooks),
+                          cross_layer=L if kw["transcode"] else 0, optimizer="adam", lr=1e-3, lr_warmup_steps=1,
+                          log_to_wandb=False)
+        tr = TPTrainer(cfg, batches, device=DEV, num_batches=10)
+        with torch.no_grad():
+            gg = torch.Generator(device=DEV).manual_seed(1)
+            for sae in tr.saes.values():
+                for n, p in sae.named_parameters():
+                    if n.startswith("W_dec") and kw["transcode"]:
+                        p.copy_((0.02 * torch.randn(p.shape, generator=gg, device=DEV)).to(p.dtype))
+        fv = [{h: float(v) for h, v in tr.step(b).items()} for b in batches]
+        return fv, {f"{h}.{n}": p.detach().float().clone() for h, sae in tr.saes.items() for n, p in sae.named_parameters()}
+
+    fv_a, pa = run(True)
+    fv_b, pb = run(False)
+    for a, b in zip(fv_a, fv_b):
+        for h in hooks:
+            assert abs(a[h] - b[h]) <= 1e-2 * abs(b[h]), (h, a[h], b[h])
+    for n in pa:
+        err = float((pa[n] - pb[n]).norm() / (pb[n].norm() + 1e-12))
+        assert err < 1e-2, (n, err)
