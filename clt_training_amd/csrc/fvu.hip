@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void fvu_colsum_kernel(const void* __restrict_
   const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (c < d) {
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
     for (int64_t r = r0; r < r1; ++r) {
       const bool m = mask ? mask[r] != 0 : true;
       float v[4];
@@ -77,20 +77,28 @@ __global__ void fvu_total_kernel(const float* __restrict__ psc, int NB, float* _
   }
 }
 
-// grid = column blocks of 64: the 4 waves of a block take quarters of the row blocks, then combine in LDS
-__global__ __launch_bounds__(256) void fvu_mean_kernel(const float* __restrict__ pcol, const float* __restrict__ pcnt,
-                                                       int NB, int d, float* __restrict__ mean) {
-  __shared__ float red[4][64];
+// grid = column blocks of 64: the 16 waves of a block take sixteenths of the row blocks (loads issued 8 at a time),
+// then combine through LDS in a fixed order
+__global__ __launch_bounds__(1024) void fvu_mean_kernel(const float* __restrict__ pcol, const float* __restrict__ pcnt,
+                                                        int NB, int d, float* __restrict__ mean) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  const int per = (NB + 3) / 4;
+  const int per = (NB + 15) / 16;
   const int b0 = w * per, b1 = min(NB, b0 + per);
   float s = 0.f;
-  if (c < d)
+  if (c < d) {
+#pragma unroll 8
     for (int b = b0; b < b1; ++b) s += pcol[(int64_t)b * d + c];
+  }
   red[w][lane] = s;
   __syncthreads();
-  if (w == 0 && c < d) mean[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);  // column SUM
+  if (w == 0 && c < d) {  // column SUM
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][lane];
+    mean[c] = t;
+  }
   if (blockIdx.x == 0 && w == 1) {  // the consumer divides by the (possibly all-reduced) count in mean[d]
     float cnt = 0.f;
     for (int b = lane; b < NB; b += 64) cnt += pcnt[b];
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(256) void fvu_partial_kernel(const void* __restrict
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
     const float4 mu4 = *reinterpret_cast<const float4*>(mean + c);
     const float mu[4] = {mu4.x * inv_cnt, mu4.y * inv_cnt, mu4.z * inv_cnt, mu4.w * inv_cnt};
-#pragma unroll 4
+#pragma unroll 8
     for (int64_t r = r0; r < r1; ++r) {
       const bool m = mask ? mask[r] != 0 : true;
       float yy[4], yh[4];
@@ -171,9 +179,11 @@ __global__ __launch_bounds__(256) void fvu_grad_kernel(const void* __restrict__ 
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
     const int64_t r = i / d;  // d % 4 == 0: the 4 elements share a row
     const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
-    float g[4];
+    float g[4], yy[4], yh[4];
+    ld4(y, y_dtype, i, yy);
+    ld4(yhat, yh_dtype, i, yh);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) g[q] = coef * m * (ld(y, y_dtype, i + q) - ld(yhat, yh_dtype, i + q));
+    for (int q = 0; q < 4; ++q) g[q] = coef * m * (yy[q] - yh[q]);
     if constexpr (sizeof(GT) == 2) {
       uint2 u;
       u.x = pack_bf16x2(g[0], g[1]);
@@ -216,7 +226,7 @@ extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int
   float* mean = pcnt + (NB + 3) / 4 * 4;  // float4 loads of the column sums: keep 16-byte alignment
   float* psc = mean + d + 4;
   hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB, (d + 1023) / 1024), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
-  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 63) / 64), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
+  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)pcol, (const float*)pcnt, NB,
                      d, mean);
   hipLaunchKernelGGL(fvu_partial_kernel, dim3(NB), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d, rpb,
                      (const float*)mean, psc);
@@ -249,7 +259,7 @@ extern "C" int clt_fvu_colsum(const void* y, int y_dtype, const uint8_t* mask, i
   float* pcol = reinterpret_cast<float*>(workspace);
   float* pcnt = pcol + (size_t)NB * d;
   hipLaunchKernelGGL(fvu_colsum_kernel, dim3(NB, (d + 1023) / 1024), dim3(256), 0, st, y, y_dtype, mask, N, d, rpb, pcol, pcnt);
-  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 63) / 64), dim3(256), 0, st, (const float*)pcol, (const float*)pcnt, NB,
+  hipLaunchKernelGGL(fvu_mean_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, (const float*)pcol, (const float*)pcnt, NB,
                      d, colsum_count);
   CLT_CHECK_LAUNCH("clt_fvu_colsum");
   return CLT_OK;

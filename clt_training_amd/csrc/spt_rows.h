@@ -735,12 +735,7 @@ static int launch_spt(int ch, hipStream_t st, const int32_t* perm, const int32_t
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
     case 2:
-      if (ADAM && BWD) {
-        static const int tune_u = getenv("CLT_ROWS_U") ? atoi(getenv("CLT_ROWS_U")) : 4;  // TUNING ONLY
-        if (tune_u == 2) { LAUNCH(2, 2); }
-        else if (tune_u == 3) { LAUNCH(2, 3); }
-        else { LAUNCH(2, 4); }
-      } else if (ADAM) { LAUNCH(2, 4); }  // fewer gathers in flight, more waves: the state streams need the occupancy
+      if (ADAM) { LAUNCH(2, 4); }  // fewer gathers in flight, more waves: the state streams need the occupancy
       else { LAUNCH(2, 8); }
       break;
     case 4: LAUNCH(4, 4); break;
