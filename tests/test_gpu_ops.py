@@ -256,6 +256,58 @@ def test_long_rows_prereduced(ops):
             torch.testing.assert_close(gs2, gs1, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,d,M,k,ns,lo,hi", [(1, 64, 33, 1, 1, 0, 33), (3, 104, 301, 70, 2, 0, 301), (5, 768, 127, 3, 4, 64, 65),
+                                              (7, 64, 50, 8, 3, 50, 50 + 0), (2, 2048, 9, 9, 2, 0, 9)])
+def test_decode_edges(ops, dtype, N, d, M, k, ns, lo, hi):
+    """Ragged and degenerate shapes through the fan-out and row-pass kernels: one token, k = 1, k > 64 (several
+    64-entry chunks), odd row counts, a one-row shard, an EMPTY shard (every entry belongs to another rank: outputs
+    must be the bias / zeros and every table row must still get its (zero-gradient) Adam update)."""
+    g = torch.Generator().manual_seed(N * 7 + k)
+    if hi == lo:  # empty shard: a table of 4 rows that no index names
+        lo, hi, M_tab = M, M + 4, M + 4
+    else:
+        M_tab = M
+    Ml = hi - lo
+    G = torch.randn(N, d, generator=g).to(dtype).to(DEV)
+    bias = torch.randn(d, generator=g).to(DEV)
+    srcs, ref_y = [], torch.zeros(N, d)
+    for _ in range(ns):
+        Wf = (torch.randn(M_tab, d, generator=g) / math.sqrt(d)).to(dtype)
+        v = torch.rand(N, k, generator=g)
+        idx = torch.stack([torch.randperm(M, generator=g)[:k] for _ in range(N)])
+        own = (idx >= lo) & (idx < hi)
+        ref_y += O.decode_fwd(idx.clamp(max=M_tab - 1), v * own, Wf.float())
+        srcs.append(dict(idx=idx.to(DEV), v=v.to(DEV), W=Wf[lo:hi].contiguous().to(DEV), lat_begin=lo, own=own))
+    tol = FP32 if dtype == torch.float32 else BF16
+    y = ops.decode_fwd_multi([{a: b for a, b in s_.items() if a != "own"} for s_ in srcs], bias=bias)
+    torch.testing.assert_close(y.float().cpu(), ref_y + bias.cpu(), **tol)
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    for s_ in srcs:
+        seg = ops.segments_build(s_["idx"], Ml, lat_begin=lo)
+        assert int(seg.offsets[-1]) == int(s_["own"].sum())
+        acts = (s_["v"] * s_["own"].to(DEV)).contiguous()
+        W0 = s_["W"].clone()
+        # plain gradient, then the fused Adam form: both against the oracle's dense gradient
+        ga = torch.zeros(N, k, device=DEV)
+        gW, _, _ = ops.decode_bwd_rows(seg, acts.view(-1), s_["v"], s_["W"], G, ga)
+        loc = (s_["idx"].cpu() - lo).clamp(0, Ml - 1)
+        gW_ref = torch.zeros(Ml, d).index_add_(0, loc.reshape(-1), ((s_["v"].cpu() * s_["own"]).reshape(-1, 1)
+                                                                      * G.float().cpu().repeat_interleave(k, 0)))
+        torch.testing.assert_close(gW.float().cpu(), gW_ref, **tol)
+        ga_ref = (W0.float().cpu()[loc] * G.float().cpu().unsqueeze(1)).sum(-1) * s_["own"]
+        torch.testing.assert_close(ga.cpu(), ga_ref, rtol=1e-3, atol=1e-3)
+        m_, v_ = torch.zeros_like(W0), torch.zeros_like(W0)
+        ga2 = torch.zeros(N, k, device=DEV)
+        ops.decode_bwd_rows(seg, acts.view(-1), s_["v"], s_["W"], G, ga2, adam=dict(m=m_, v=v_, step=1, **hp))
+        assert torch.equal(ga2, ga)
+        g_r = gW.float()
+        torch.testing.assert_close(m_.float(), 0.1 * g_r, rtol=1e-2, atol=1e-6)
+        torch.testing.assert_close(v_.float(), 0.001 * g_r * g_r, rtol=2e-2, atol=1e-9)
+        moved = (s_["W"].float() - W0.float()).abs()
+        assert bool(((moved > 0) == (g_r != 0)).all()) or dtype == torch.bfloat16
+
+
 def test_segments_skewed(ops):
     """One latent active on every token (long segment) + many empty latents."""
     N, k, M, d = 700, 8, 512, 64
