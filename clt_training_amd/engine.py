@@ -185,6 +185,57 @@ class ShardedCoder(nn.Module):
         del multi
         return sc
 
+    def to_full(self, comm: Optional["Comm"] = None):
+        """The inverse of ``from_full``: gather the latent shards of the group (all ranks take part in the collectives)
+        into an unsharded ``SparseCoder`` on the CPU with the reference's parameter names.  Returned on rank 0 only
+        (None elsewhere).  Replaces the TP branch of save_sharded (utils.py:280-360: shards gathered to rank 0)."""
+        from .sparse_coder import SparseCoder
+
+        comm = comm or Comm(enabled=False)
+        assert comm.world == self.tp
+
+        def rows(t):  # latent-sharded along dim 0
+            return comm.all_gather_rows(t.detach()).cpu()
+
+        full = {"encoder.weight": rows(self.W_enc), "encoder.bias": rows(self.b_enc)}
+        for i in range(self.n_slots):
+            full[f"W_decs.{i}"] = rows(self.W_decs[i])
+            full[f"b_decs.{i}"] = self.b_decs[i].detach().cpu()
+            if self.W_skips is not None:
+                full[f"W_skips.{i}"] = self.W_skips[i].detach().cpu()
+            full[f"post_encs.{i}"] = rows(self.post_encs[i])
+            if self.post_enc_scales is not None:
+                full[f"post_enc_scales.{i}"] = rows(self.post_enc_scales[i])
+        if comm.rank != 0:
+            return None
+        sae = SparseCoder(self.d_in, self.cfg, "cpu", dtype=torch.float32)
+        sd = sae.state_dict()
+        with torch.no_grad():
+            for name, t in full.items():
+                single = name.rsplit(".", 1)[0][:-1] if name.split(".")[0].endswith("s") and name[-1].isdigit() else None
+                target = name if name in sd else (single if single in sd and name.endswith(".0") else None)
+                if target is None:
+                    raise KeyError(f"{name}: no counterpart in the unsharded module")
+                sd[target].copy_(t.to(sd[target].dtype))
+            if self.cfg.normalize_io:
+                sae.in_norm.copy_(self.in_norm.cpu())
+                sae.out_norm.copy_(self.out_norm.cpu())
+        return sae
+
+    def save_to_disk(self, path, comm: Optional["Comm"] = None):
+        """``sae.safetensors`` + ``cfg.json`` in the reference's unsharded format (sparse_coder.py:593-612)."""
+        sae = self.to_full(comm)
+        if sae is not None:
+            sae.save_to_disk(path)
+
+    @staticmethod
+    def load_from_disk(path, device, rank: int = 0, tp: int = 1) -> "ShardedCoder":
+        """Every rank reads the unsharded checkpoint (with the reference's imputation rules, SparseCoder.load_state)
+        and keeps its latent range."""
+        from .sparse_coder import SparseCoder
+
+        return ShardedCoder.from_full(SparseCoder.load_from_disk(path, "cpu"), rank, tp, device)
+
     def replicated_parameters(self):
         out = list(self.b_decs)
         if self.W_skips is not None:

@@ -303,9 +303,49 @@ class SparseCoder(nn.Module):
             d_in = cfg_dict.pop("d_in")
             cfg = SparseCoderConfig.from_dict(cfg_dict, drop_extra_fields=True)
         sae = SparseCoder(d_in, cfg, device=device, decoder=decoder, dtype=torch.float32)
-        state = load_file(str(path / "sae.safetensors"), device=str(device))
-        sae.load_state_dict({k: v for k, v in state.items() if k in sae.state_dict()}, strict=False)
+        sae.load_state(path)
         return sae
+
+    def load_state(self, path, strict: bool = False):
+        """sparse_coder.py:518-592: read ``sae.safetensors`` and IMPUTE what an older / single-target checkpoint lacks:
+        missing post-encoder vectors keep this module's initial values; a checkpoint with one ``W_dec`` / ``b_dec`` /
+        ``W_skip`` loaded into a per-target module fills slot 0 and leaves the other slots at their initial values."""
+        from safetensors.torch import load_file
+
+        mine = self.state_dict()
+        state = load_file(str(Path(path) / "sae.safetensors"), device=str(self.device))
+
+        def keep_initial(stem):  # "post_enc" / "post_enc_scale": single vector, or one per target
+            if hasattr(self, stem) and not hasattr(self, stem + "s") and stem not in state:
+                state[stem] = getattr(self, stem).detach().clone()
+            plural = getattr(self, stem + "s", None)
+            if plural is not None and not any(f"{stem}s.{i}" in state for i in range(len(plural))):
+                for i, t in enumerate(plural):
+                    state[f"{stem}s.{i}"] = t.detach().clone()
+
+        def spread_single(stem):  # "W_dec" / "b_dec" / "W_skip" -> slot 0 of the per-target list
+            plural = getattr(self, stem + "s", None)
+            if plural is None or any(f"{stem}s.{i}" in state for i in range(len(plural))):
+                return
+            if stem in state:
+                state[f"{stem}s.0"] = state[stem]
+            for i, t in enumerate(plural):
+                if i > 0 and t is not None:
+                    state[f"{stem}s.{i}"] = t.detach().clone()
+
+        keep_initial("post_enc")
+        keep_initial("post_enc_scale")
+        spread_single("W_dec")
+        if self.cfg.skip_connection:
+            spread_single("W_skip")
+        spread_single("b_dec")
+        ordered = {k: state[k] for k in mine if k in state}
+        # the singular names alias slot 0 (self.W_dec = self.W_decs[0]): keep the two views of one storage consistent
+        for stem in ("W_dec", "b_dec", "W_skip"):
+            if f"{stem}s.0" in ordered and stem in mine:
+                ordered[stem] = ordered[f"{stem}s.0"]
+        self.load_state_dict(ordered, strict=strict)
+        return self
 
     def save_to_disk(self, path):
         from safetensors.torch import save_file

@@ -152,6 +152,58 @@ class TPTrainer:
         self.global_step += 1
         return self.last_fvu
 
+    # ------------------------------------------------------------------ checkpoint (trainer.py:910-964, 258-348)
+    def save(self, path):
+        """``{path}/{hookpoint}/sae.safetensors + cfg.json`` in the reference's unsharded format (the latent shards are
+        gathered to rank 0), ``lr_scheduler_0.pt``, ``state.pt`` (global_step) and ``rank_{r}_state.pt``
+        (num_tokens_since_fired) as the reference writes them.  The optimizer state stays sharded:
+        ``optimizer_0.rank{r}.pt`` per rank (the reference gathers and flattens it, utils.py:193-277; resuming
+        on a different tp degree is not supported here)."""
+        from pathlib import Path
+
+        path = Path(path)
+        rank = self.comm.rank
+        if rank == 0:
+            path.mkdir(parents=True, exist_ok=True)
+        if self.comm.world > 1:
+            dist.barrier(group=self.comm.group)
+        for name, sae in self.saes.items():
+            sae.save_to_disk(path / name, self.comm)
+        opt = self.optimizers[0]
+        torch.save({"state": opt.state_dict(), "step": getattr(opt, "_step", None)}, path / f"optimizer_0.rank{rank}.pt")
+        torch.save({"num_tokens_since_fired": {h: t.cpu() for h, t in self.num_tokens_since_fired.items()}},
+                   path / f"rank_{rank}_state.pt")
+        if rank == 0:
+            torch.save(self.lr_schedulers[0].state_dict(), path / "lr_scheduler_0.pt")
+            torch.save({"global_step": self.global_step}, path / "state.pt")
+        if self.comm.world > 1:
+            dist.barrier(group=self.comm.group)
+
+    def load_state(self, path):
+        """Resume from ``save(path)`` on the same tp degree."""
+        from pathlib import Path
+
+        path = Path(path)
+        rank = self.comm.rank
+        with torch.no_grad():
+            for name, sae in self.saes.items():
+                loaded = ShardedCoder.load_from_disk(path / name, self.device, rank, self.comm.world)
+                for p, q in zip(sae.parameters(), loaded.parameters()):
+                    p.copy_(q.to(p.dtype))
+                for (_, b), (_, c) in zip(sae.named_buffers(), loaded.named_buffers()):
+                    b.copy_(c)
+        opt = self.optimizers[0]
+        blob = torch.load(path / f"optimizer_0.rank{rank}.pt", map_location=self.device, weights_only=True)
+        opt.load_state_dict(blob["state"])
+        if blob["step"] is not None:
+            opt._step = blob["step"]
+        self.lr_schedulers[0].load_state_dict(torch.load(path / "lr_scheduler_0.pt", weights_only=True))
+        self.global_step = torch.load(path / "state.pt", weights_only=True)["global_step"]
+        fired = torch.load(path / f"rank_{rank}_state.pt", map_location=self.device, weights_only=True)
+        for h, t in fired["num_tokens_since_fired"].items():
+            self.num_tokens_since_fired[h].copy_(t)
+        return self
+
     def fit(self, log=None):
         for batch in self.dataset:
             fv = self.step(batch)

@@ -1,0 +1,61 @@
+"""Checkpoint format: ``sae.safetensors`` + ``cfg.json`` per hookpoint with the reference's
+parameter names, the imputation rules of sparse_coder.py:518-592, and the gather of latent shards into the unsharded file."""
+import json
+
+import torch
+
+from clt_training_amd import SparseCoder, SparseCoderConfig
+from clt_training_amd.engine import ShardedCoder
+
+
+def _randomise(sae, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in sae.parameters():
+            p.copy_(torch.randn(p.shape, generator=g))
+    return sae
+
+
+def test_round_trip_keeps_reference_names(tmp_path):
+    cfg = SparseCoderConfig(transcode=True, expansion_factor=4, k=4, skip_connection=True, post_encoder_scale=True,
+                            normalize_io=True, n_targets=3, n_sources=1)
+    sae = _randomise(SparseCoder(16, cfg, "cpu", dtype=torch.float32), 0)
+    sae.save_to_disk(tmp_path / "a")
+    with open(tmp_path / "a" / "cfg.json") as f:
+        meta = json.load(f)
+    assert meta["d_in"] == 16 and meta["k"] == 4 and meta["n_targets"] == 3
+    back = SparseCoder.load_from_disk(tmp_path / "a")
+    want = {"encoder.weight", "encoder.bias", "W_dec", "b_dec", "W_skip", "in_norm", "out_norm"}
+    want |= {f"{s}.{i}" for s in ("W_decs", "b_decs", "W_skips", "post_encs", "post_enc_scales") for i in range(3)}
+    assert set(back.state_dict()) == want
+    for (n, a), (m, b) in zip(sae.state_dict().items(), back.state_dict().items()):
+        assert n == m and torch.equal(a, b), n
+
+
+def test_single_target_checkpoint_is_imputed_into_per_target_module(tmp_path):
+    one = _randomise(SparseCoder(16, SparseCoderConfig(transcode=True, expansion_factor=4, k=4, skip_connection=True), "cpu",
+                                 dtype=torch.float32), 1)
+    one.save_to_disk(tmp_path / "one")
+    cfg3 = SparseCoderConfig(transcode=True, expansion_factor=4, k=4, skip_connection=True, post_encoder_scale=True,
+                             n_targets=3, n_sources=1)
+    three = SparseCoder(16, cfg3, "cpu", dtype=torch.float32)
+    three.load_state(tmp_path / "one")
+    assert torch.equal(three.W_decs[0], one.W_dec) and three.W_dec is three.W_decs[0]
+    assert torch.equal(three.b_decs[0], one.b_dec) and torch.equal(three.W_skips[0], one.W_skip)
+    assert float(three.W_decs[1].detach().abs().sum()) == 0 and float(three.b_decs[2].detach().abs().sum()) == 0
+    # post-encoder vectors the checkpoint lacks keep their initial values (ones for slot 0 of the scale, zeros after)
+    assert bool((three.post_enc_scales[0] == 1).all()) and bool((three.post_enc_scales[1] == 0).all())
+    assert torch.equal(three.encoder.weight, one.encoder.weight)
+
+
+def test_sharded_coder_gathers_into_the_unsharded_file(tmp_path):
+    cfg = SparseCoderConfig(transcode=True, expansion_factor=4, k=4, skip_connection=True, post_encoder_scale=True,
+                            n_targets=2, n_sources=1)
+    sae = _randomise(SparseCoder(16, cfg, "cpu", dtype=torch.float32), 2)
+    ShardedCoder.from_full(sae, 0, 1, "cpu").save_to_disk(tmp_path / "s")
+    back = SparseCoder.load_from_disk(tmp_path / "s")
+    for (n, a), (m, b) in zip(sae.state_dict().items(), back.state_dict().items()):
+        assert n == m and torch.equal(a, b), n
+    half = ShardedCoder.load_from_disk(tmp_path / "s", "cpu", rank=1, tp=2)
+    assert torch.equal(half.W_enc, sae.encoder.weight[32:]) and torch.equal(half.W_decs[1], sae.W_decs[1][32:])
+    assert torch.equal(half.b_decs[1], sae.b_decs[1]) and half.lat_begin == 32

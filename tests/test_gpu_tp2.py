@@ -12,3 +12,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("case", list(CASES))
 def test_tp2_hip_matches_single_process_oracle(case, tmp_path):
     run_case(case, tmp_path, device="cuda")
+
+
+def test_tp2_hip_checkpoint_resume(tmp_path):
+    """Save after two steps, resume in a fresh trainer (HIP Adam state incl. its step counter), third step unchanged."""
+    run_case("clt_skip_scale_norm_div", tmp_path, device="cuda", resume=True)

@@ -72,7 +72,7 @@ def _oracle_layers(saes):
     return layers
 
 
-def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir, device="cpu"):
+def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir, device="cpu", resume=False):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -98,7 +98,16 @@ def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir, device="cpu"):
                    optimizer_cls=adam_cls, coders=coders)
     Nr = N // world
     fv = []
-    for xs, ys, m in steps:
+    for s_i, (xs, ys, m) in enumerate(steps):
+        if resume and s_i == 2:
+            # checkpoint after two steps (shards gathered into the reference's unsharded sae.safetensors), then carry on
+            # in a FRESH trainer that starts from the untrained parameters and loads the checkpoint
+            tr.save(f"{out_dir}/ckpt")
+            coders = [ShardedCoder.from_full(s, rank, world, device) for s in _make_problem(sae_kw, L, cross, d, N)[0]]
+            tr = TPTrainer(cfg, [None] * 4, device=device, input_widths={h: d for h in hooks}, ops=ops,
+                           optimizer_cls=adam_cls, coders=coders)
+            tr.load_state(f"{out_dir}/ckpt")
+            assert tr.global_step == 2
         batch = {h: (xs[l][rank * Nr:(rank + 1) * Nr].to(device), ys[l][rank * Nr:(rank + 1) * Nr].to(device))
                  for l, h in enumerate(hooks)}
         batch["loss_mask"] = m[rank * Nr:(rank + 1) * Nr].to(device)
@@ -126,13 +135,13 @@ CASES = {
 }
 
 
-def run_case(case, tmp_path, device="cpu"):
+def run_case(case, tmp_path, device="cpu", resume=False):
     from oracle import clt_oracle as O
 
     sae_kw, L, cross = CASES[case]
     d, N, world = 16, 24, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, sae_kw, L, cross, d, N, str(tmp_path), device), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, sae_kw, L, cross, d, N, str(tmp_path), device, resume), nprocs=world, join=True)
     res = [torch.load(f"{tmp_path}/rank{r}.pt", weights_only=True) for r in range(world)]
     # ---- single-process oracle: 3 steps of clt_train_step + Adam with the warm-up schedule
     saes, steps = _make_problem(sae_kw, L, cross, d, N)
@@ -181,3 +190,14 @@ def run_case(case, tmp_path, device="cpu"):
 @pytest.mark.parametrize("case", list(CASES))
 def test_tp2_matches_single_process_oracle(case, tmp_path):
     run_case(case, tmp_path)
+
+
+def test_tp2_checkpoint_resume(tmp_path):
+    """trainer.py:910-964 / 258-348 on the sharded trainer: save after two steps (latent shards gathered into the
+    reference's unsharded ``sae.safetensors`` + ``cfg.json``; per-rank optimizer state), resume in a fresh trainer,
+    and the third step still matches the uninterrupted single-process oracle."""
+    run_case("clt_skip_scale_norm_div", tmp_path, resume=True)
+    from safetensors.torch import load_file
+
+    sd = load_file(f"{tmp_path}/ckpt/h.0/sae.safetensors")
+    assert sd["encoder.weight"].shape == (64, 16) and "W_decs.1" in sd and "post_enc_scales.0" in sd
