@@ -6,7 +6,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from clt_training_amd import hip_ops as ops
 from tools.bench_kernels import timeit
 
-N, d, M, k = 8192, 768, 98304, 32
+import os
+N, d, M, k = int(os.environ.get('BN', 8192)), 768, int(os.environ.get('BM', 98304)), 32
 torch.manual_seed(0)
 x = (torch.randn(N, d, device="cuda") + 0.1 * torch.randn(d, device="cuda")).bfloat16()
 W = (torch.randn(M, d, device="cuda") / d**0.5).bfloat16()
