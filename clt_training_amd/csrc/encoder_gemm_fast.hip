@@ -466,10 +466,7 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
     // list l = ((virtual tile * 2 + wm) * 2 + h); position pos = i * 16 + g * 4 + q
     const int vt = l >> 2, wm = (l >> 1) & 1, hh = l & 1;
     const unsigned lat_base = (unsigned)lt_actual(vt, LT_REST, lt_S) * 256u + wm * 128 + 4 * hh;
-    int cmax = c;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
-    for (int e = 0; e < cmax; ++e) {
+    for (int e = 0; __ballot(e < c) != 0ull; ++e) {  // while some lane's list still has an entry
       float v = -1.f;
       unsigned col = 0;
       if (e < c) {
