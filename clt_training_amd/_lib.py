@@ -57,7 +57,9 @@ SIGNATURES = {
     "clt_decode_bwd_rows": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
                                    _vp, _vp, _vp]),
     "clt_decode_bwd_rows_adam": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
-                                        _i32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i64, _vp, _sz, _vp]),
+                                        _i32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _i64, _vp, _sz, _vp]),
+    "clt_rows_unit_norm": (_i32, [_vp, _i32, _i64, _i32, _f32, _vp]),
+    "clt_rows_project_out": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp]),
     "clt_segment_sum": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "clt_fvu_workspace_bytes": (_sz, [_i64, _i32]),
     "clt_fvu_fwd_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _sz, _vp]),

@@ -57,8 +57,9 @@ extern "C" int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offs
                                         const void* v, int v_dtype, const float* post_enc, const float* post_scale,
                                         const void* G, int g_dtype, int d, int k, void* W, void* exp_avg,
                                         void* exp_avg_sq, int w_dtype, float* grad_acts, float* g_post, float* g_scale,
-                                        float lr, float b1, float b2, float eps, int step, int64_t n_entries,
-                                        void* workspace, size_t workspace_bytes, clt_stream_t stream) {
+                                        float lr, float b1, float b2, float eps, int step, int project_out,
+                                        int64_t n_entries, void* workspace, size_t workspace_bytes,
+                                        clt_stream_t stream) {
   int ch;
   int rc = check_rows_args("clt_decode_bwd_rows_adam", perm, offsets, M, acts, v, v_dtype, post_scale, G, g_dtype, d, k,
                            W, w_dtype, grad_acts, g_scale, &ch);
@@ -66,7 +67,7 @@ extern "C" int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offs
   CLT_CHECK_ARG(exp_avg && exp_avg_sq && aligned16(exp_avg) && aligned16(exp_avg_sq) && step >= 1,
                 "clt_decode_bwd_rows_adam: bad optimizer state");
   BwdActs bw = {v, v_dtype, post_enc, post_scale, grad_acts, g_post, g_scale, nullptr};
-  const AdamRows ad = make_adam_rows(exp_avg, exp_avg_sq, lr, b1, b2, eps, step);
+  const AdamRows ad = make_adam_rows(exp_avg, exp_avg_sq, lr, b1, b2, eps, step, project_out != 0);
   hipStream_t st = (hipStream_t)stream;
   const bool lds_ok = rows_lds_ok(d, dtype_size(w_dtype), ch);
   if (lds_ok && g_dtype == CLT_BF16)
@@ -82,5 +83,128 @@ extern "C" int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offs
     return rc;
   }
   CLT_CHECK_LAUNCH("clt_decode_bwd_rows_adam");
+  return CLT_OK;
+}
+
+// ---- SAE extras (sparse_coder.py:687-711; trainer.py:595-596, 793-795): row-wise passes over the decoder table, one wave
+//      per row, 16-byte chunks, fp32 arithmetic.  HBM-bound: one read + one write of the table (the reference's torch
+//      expressions make 3-6 passes).
+namespace clt {
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void rows_unit_norm_kernel(T* __restrict__ W, int64_t M, int d, float eps) {
+  constexpr int E = Chunk<T>::E;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunks = d / E;
+  T* wr = W + row * (int64_t)d;
+  float w[CH][E];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      load_row_chunk<T, E>(wr + ch * E, w[c]);
+#pragma unroll
+      for (int e = 0; e < E; ++e) ss = fmaf(w[c][e], w[c][e], ss);
+    }
+  }
+  ss = wave_sum_dpp(ss);
+  float nrm = sqrtf(ss);
+  if (sizeof(T) == 2) nrm = bf16_bits_to_f32(f32_to_bf16_bits(nrm));  // torch.norm returns the table's dtype
+  const float den = nrm + eps;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) w[c][e] = w[c][e] / den;
+      store_row_chunk<T, E>(wr + ch * E, w[c]);
+    }
+  }
+}
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void rows_project_out_kernel(T* __restrict__ G, const T* __restrict__ W, int64_t M,
+                                                               int d) {
+  constexpr int E = Chunk<T>::E;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunks = d / E;
+  T* gr = G + row * (int64_t)d;
+  const T* wr = W + row * (int64_t)d;
+  float g[CH][E], w[CH][E];
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      load_row_chunk<T, E>(gr + ch * E, g[c]);
+      load_row_chunk<T, E>(wr + ch * E, w[c]);
+#pragma unroll
+      for (int e = 0; e < E; ++e) dot = fmaf(g[c][e], w[c][e], dot);
+    }
+  }
+  dot = wave_sum_dpp(dot);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) g[c][e] = project_elem<sizeof(T) == 2>(g[c][e], w[c][e], dot);
+      store_row_chunk<T, E>(gr + ch * E, g[c]);
+    }
+  }
+}
+
+template <typename T>
+static int launch_rows_simple(int which, void* A, const void* B, int64_t M, int d, float eps, hipStream_t st) {
+  const int E = Chunk<T>::E;
+  int chunks = d / E, ch = (chunks + 63) / 64;
+  ch = ch <= 1 ? 1 : ch <= 2 ? 2 : ch <= 4 ? 4 : ch <= 8 ? 8 : ch <= 16 ? 16 : -1;
+  if (ch < 0 || d % E != 0) return CLT_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((M + 3) / 4));
+#define LAUNCH(CH)                                                                                               \
+  do {                                                                                                           \
+    if (which == 0) hipLaunchKernelGGL((rows_unit_norm_kernel<T, CH>), grid, dim3(256), 0, st, (T*)A, M, d, eps); \
+    else hipLaunchKernelGGL((rows_project_out_kernel<T, CH>), grid, dim3(256), 0, st, (T*)A, (const T*)B, M, d); \
+  } while (0)
+  switch (ch) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    default: LAUNCH(16); break;
+  }
+#undef LAUNCH
+  return CLT_OK;
+}
+
+}  // namespace clt
+
+extern "C" int clt_rows_unit_norm(void* W, int w_dtype, int64_t M, int d, float eps, clt_stream_t stream) {
+  CLT_CHECK_ARG(W && aligned16(W) && M > 0 && d > 0 && valid_dtype(w_dtype), "clt_rows_unit_norm: bad argument");
+  const int rc = w_dtype == CLT_BF16 ? launch_rows_simple<bf16_t>(0, W, nullptr, M, d, eps, (hipStream_t)stream)
+                                     : launch_rows_simple<float>(0, W, nullptr, M, d, eps, (hipStream_t)stream);
+  if (rc != CLT_OK) {
+    set_error("clt_rows_unit_norm: unsupported width d=%d", d);
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_rows_unit_norm");
+  return CLT_OK;
+}
+
+extern "C" int clt_rows_project_out(void* G, const void* W, int dtype, int64_t M, int d, clt_stream_t stream) {
+  CLT_CHECK_ARG(G && W && aligned16(G) && aligned16(W) && M > 0 && d > 0 && valid_dtype(dtype),
+                "clt_rows_project_out: bad argument");
+  const int rc = dtype == CLT_BF16 ? launch_rows_simple<bf16_t>(1, G, W, M, d, 0.f, (hipStream_t)stream)
+                                   : launch_rows_simple<float>(1, G, W, M, d, 0.f, (hipStream_t)stream);
+  if (rc != CLT_OK) {
+    set_error("clt_rows_project_out: unsupported width d=%d", d);
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_rows_project_out");
   return CLT_OK;
 }

@@ -42,10 +42,21 @@ struct AdamRows {
   void* m;
   void* v;
   float step_size, b1, b2, inv_sqrt_bc2, eps;
+  int project;  // SAE with a unit-norm decoder: remove the gradient's component along the row first
+                // (remove_gradient_parallel_to_decoder_directions, sparse_coder.py:696-711)
 };
 
+// g - (g . w) w for one row chunk, with the row's dot product already reduced; one rounding to the gradient dtype
+// (the reference updates W_dec.grad in place).  Shared by the fused row passes and clt_rows_project_out.
+template <bool BF16>
+__device__ __forceinline__ float project_elem(float g, float w, float dot) {
+  const float r = fmaf(-dot, w, g);
+  return BF16 ? bf16_bits_to_f32(f32_to_bf16_bits(r)) : r;
+}
+
 // The same host arithmetic as clt_adam_step (adam.hip): bias corrections in double, one rounding each.
-static inline AdamRows make_adam_rows(void* m, void* v, float lr, float b1, float b2, float eps, int step) {
+static inline AdamRows make_adam_rows(void* m, void* v, float lr, float b1, float b2, float eps, int step,
+                                      int project = 0) {
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
   AdamRows ad;
@@ -56,6 +67,7 @@ static inline AdamRows make_adam_rows(void* m, void* v, float lr, float b1, floa
   ad.b2 = b2;
   ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   ad.eps = eps;
+  ad.project = project;
   return ad;
 }
 
@@ -184,6 +196,24 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
       OT* orow = out + (r0 + cur) * (int64_t)d;
       if constexpr (ADAM) {
         const bool more = cur + 1 < nrows;  // wave-uniform
+        float dot = 0.f;
+        if (ad.project) {  // wave-uniform
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunks) {
+              float wv[E];
+              if constexpr (PREFETCH) unpack(pq[c], wv);
+              else load_row_chunk<OT, E>(orow + ch * E, wv);
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                const float g = sizeof(OT) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+                dot = fmaf(g, wv[e], dot);
+              }
+            }
+          }
+          dot = wave_sum_dpp(dot);
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int ch = lane + 64 * c;
@@ -204,7 +234,8 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-              const float g = sizeof(OT) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+              float g = sizeof(OT) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+              if (ad.project) g = project_elem<sizeof(OT) == 2>(g, pf[e], dot);
               adam_update(pf[e], mf[e], vf[e], g, ad.step_size, ad.b1, ad.b2, ad.inv_sqrt_bc2, ad.eps);
               acc[c][e] = 0.f;
             }
@@ -653,6 +684,22 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds
 
   // ---- the row is complete: optimizer update out of LDS
   if (!staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float dot = 0.f;
+  if (ad.project) {  // wave-uniform
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (lane + 64 * c < nchunks) {
+        float wv[E];
+        lds_chunk(0, c, wv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float g = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+          dot = fmaf(g, wv[e], dot);
+        }
+      }
+    }
+    dot = wave_sum_dpp(dot);
+  }
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int ch = lane + 64 * c;
@@ -663,7 +710,8 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds
       lds_chunk(2, c, vf);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        const float g = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+        float g = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+        if (ad.project) g = project_elem<sizeof(T) == 2>(g, pf[e], dot);
         adam_update(pf[e], mf[e], vf[e], g, ad.step_size, ad.b1, ad.b2, ad.inv_sqrt_bc2, ad.eps);
       }
       store_row_chunk<T, E>(out + roff + ch * E, pf);

@@ -495,6 +495,10 @@ class CLTEngine:
             if rows_pass:
                 W = li.W_decs[t]
                 h = self._fused_state(W, acc_steps)
+                if h is not None and li.cfg.normalize_decoder and not li.cfg.transcode:
+                    # unit-norm SAE decoder (sparse_coder.py:696-711): the finished gradient row is projected inside the
+                    # pass; without the fused optimizer the caller projects W.grad before its step (tp.TPTrainer.step)
+                    h = dict(h, project=True)
                 gW, gp, gs = ops.decode_bwd_rows(st.seg, st.acts.pop(t).view(-1), st.v, W.data, Gi, st.gv,
                                                  post_enc=li.post_encs[t], post_scale=ps, want_g_post=need_pe, adam=h)
                 if gW is not None:

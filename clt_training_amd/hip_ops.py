@@ -348,8 +348,23 @@ def decode_bwd_rows(seg: Segments, acts: Tensor, v: Tensor, W: Tensor, G: Tensor
     ws = workspace(W.device, _lib.load().clt_rows_workspace_bytes(n, d), "rows")  # long-row partials
     _call("clt_decode_bwd_rows_adam", *head, _ptr(W), _ptr(m_), _ptr(v_), _dt(W), _ptr(grad_acts), _ptr(g_post),
           _ptr(g_scale), float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]), float(adam["eps"]),
-          int(adam["step"]), n, _ptr(ws), ws.numel(), _stream(W))
+          int(adam["step"]), int(bool(adam.get("project", False))), n, _ptr(ws), ws.numel(), _stream(W))
     return None, g_post, g_scale
+
+
+def rows_unit_norm(W: Tensor, eps: Optional[float] = None) -> Tensor:
+    """In place W[r,:] /= (||W[r,:]|| + eps) (set_decoder_norm_to_unit_norm, sparse_coder.py:687-694)."""
+    assert W.dim() == 2 and W.is_contiguous()
+    eps = torch.finfo(W.dtype).eps if eps is None else eps
+    _call("clt_rows_unit_norm", _ptr(W), _dt(W), W.shape[0], W.shape[1], float(eps), _stream(W))
+    return W
+
+
+def rows_project_out(G: Tensor, W: Tensor) -> Tensor:
+    """In place G[r,:] -= (G[r,:] . W[r,:]) W[r,:] (remove_gradient_parallel_to_decoder_directions, :696-711)."""
+    assert G.shape == W.shape and G.dtype == W.dtype and G.is_contiguous() and W.is_contiguous()
+    _call("clt_rows_project_out", _ptr(G), _ptr(W), _dt(W), W.shape[0], W.shape[1], _stream(W))
+    return G
 
 
 def segment_sum(seg: Segments, a: Tensor, b: Optional[Tensor] = None):

@@ -413,7 +413,10 @@ class SparseCoder(nn.Module):
     def set_decoder_norm_to_unit_norm(self):
         for W_dec in self.W_decs if hasattr(self, "W_decs") else (self.W_dec,):
             assert W_dec is not None, "Decoder weight was not initialized."
-            eps = torch.finfo(W_dec.dtype).eps
+            if W_dec.is_cuda and W_dec.data.is_contiguous():  # one HIP pass (clt_rows_unit_norm)
+                ops.rows_unit_norm(W_dec.data)
+                continue
+            eps = torch.finfo(W_dec.dtype).eps  # CPU construction (tests, checkpoint conversion)
             norm = torch.norm(W_dec.data, dim=1, keepdim=True)
             W_dec.data /= norm + eps
 
@@ -421,6 +424,11 @@ class SparseCoder(nn.Module):
     def remove_gradient_parallel_to_decoder_directions(self):
         for W_dec in self.W_decs if hasattr(self, "W_decs") else (self.W_dec,):
             assert W_dec is not None and W_dec.grad is not None
+            if W_dec.is_cuda and W_dec.grad.dtype == W_dec.dtype:  # one HIP pass (clt_rows_project_out)
+                if not W_dec.grad.is_contiguous():
+                    W_dec.grad = W_dec.grad.contiguous()
+                ops.rows_project_out(W_dec.grad, W_dec.data)
+                continue
             parallel = (W_dec.grad * W_dec.data).sum(1, keepdim=True)
             W_dec.grad -= parallel * W_dec.data
 

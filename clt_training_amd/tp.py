@@ -63,8 +63,9 @@ class TPTrainer:
         self.optimizers = [adam]
         # Decoder / encoder row gradients go straight into the optimizer update (no .grad round trip) when nothing
         # else consumes them: one micro-step per optimizer step, and no projection of the decoder gradient.
+        # (a unit-norm SAE decoder's gradient projection happens inside the same row pass: engine.layer_step)
         fuse = (hasattr(adam, "fused_rows") and cfg.grad_acc_steps * cfg.micro_acc_steps == 1
-                and not (cfg.sae.normalize_decoder and not cfg.sae.transcode) and not os.environ.get("CLT_NO_FUSED_ADAM"))
+                and not os.environ.get("CLT_NO_FUSED_ADAM"))
         self.engine.fused_opt = adam if fuse else None
         self.lr_schedulers = [WarmupLinearSchedule(adam, cfg.lr_warmup_steps, num_batches)]
         self.global_step = 0
@@ -114,7 +115,10 @@ class TPTrainer:
                 eng.first_step_init(j, x if cfg.sae.transcode else y, y)
             if sae.cfg.normalize_decoder and not cfg.sae.transcode:  # trainer.py:595-596 (row-wise: shard-local)
                 W = sae.W_decs[0]
-                W.data /= W.data.norm(dim=1, keepdim=True) + torch.finfo(W.dtype).eps
+                if hasattr(self.ops, "rows_unit_norm"):
+                    self.ops.rows_unit_norm(W.data)
+                else:
+                    W.data /= W.data.norm(dim=1, keepdim=True) + torch.finfo(W.dtype).eps
             enc = None
             if overlap:
                 if j + 1 < len(names):
@@ -136,7 +140,12 @@ class TPTrainer:
             if cfg.sae.normalize_decoder and not cfg.sae.transcode:  # sparse_coder.py:696-711 (row-wise)
                 for sae in self.saes.values():
                     W = sae.W_decs[0]
-                    W.grad -= (W.grad * W.data).sum(1, keepdim=True) * W.data
+                    if W.grad is None:
+                        continue  # projected and consumed inside the row pass (clt_decode_bwd_rows_adam, project_out)
+                    if hasattr(self.ops, "rows_project_out") and W.grad.dtype == W.dtype:
+                        self.ops.rows_project_out(W.grad, W.data)
+                    else:
+                        W.grad -= (W.grad * W.data).sum(1, keepdim=True) * W.data
             for opt in self.optimizers:
                 opt.step()
                 opt.zero_grad()

@@ -205,7 +205,19 @@ int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offsets, int64_
                              int v_dtype, const float* post_enc, const float* post_scale, const void* G, int g_dtype,
                              int d, int k, void* W, void* exp_avg, void* exp_avg_sq, int w_dtype, float* grad_acts,
                              float* g_post, float* g_scale, float lr, float b1, float b2, float eps, int step,
-                             int64_t n_entries, void* workspace, size_t workspace_bytes, clt_stream_t stream);
+                             int project_out, int64_t n_entries, void* workspace, size_t workspace_bytes,
+                             clt_stream_t stream);
+
+/* ------------------------------------------------------------------ SAE extras
+ * Plain SAEs keep unit-norm decoder rows (sparse_coder.py:687-711; trainer.py:595-596, 793-795):
+ *   clt_rows_unit_norm:   W[r,:] /= (||W[r,:]|| + eps)            (set_decoder_norm_to_unit_norm; eps = finfo(dtype).eps)
+ *   clt_rows_project_out: G[r,:] -= (G[r,:] . W[r,:]) W[r,:]      (remove_gradient_parallel_to_decoder_directions)
+ * one read + one write of the [M,d] table each (the torch expressions make 3-6 passes), in place, fp32 arithmetic,
+ * one rounding per stored value.  `project_out` != 0 in clt_decode_bwd_rows_adam applies the projection to the
+ * finished gradient row inside the row pass (bitwise equal to clt_decode_bwd_rows -> clt_rows_project_out ->
+ * clt_adam_step), so an SAE's decoder backward, projection and Adam update are ONE pass as well.              */
+int clt_rows_unit_norm(void* W, int w_dtype, int64_t M, int d, float eps, clt_stream_t stream);
+int clt_rows_project_out(void* G, const void* W, int dtype, int64_t M, int d, clt_stream_t stream);
 
 /* Per-latent sums of up to two per-entry arrays (post_enc / post_enc_scale grads: the
  * scatter-adds autograd generates for sparse_coder.py:136-140):

@@ -308,6 +308,47 @@ def test_decode_edges(ops, dtype, N, d, M, k, ns, lo, hi):
         assert bool(((moved > 0) == (g_r != 0)).all()) or dtype == torch.bfloat16
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,d", [(257, 768), (64, 4096), (33, 104)])
+def test_sae_row_extras(ops, dtype, M, d):
+    """clt_rows_unit_norm / clt_rows_project_out against the reference's torch expressions (sparse_coder.py:687-711), and
+    the projection fused into the row pass (project_out) bit for bit against plain gradient -> clt_rows_project_out ->
+    clt_adam_step."""
+    from clt_training_amd.adam import Adam
+    g = torch.Generator().manual_seed(M + d)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else BF16
+    W = torch.randn(M, d, generator=g).to(dtype)
+    ref = W.float() / (W.float().norm(dim=1, keepdim=True) + torch.finfo(dtype).eps)
+    Wn = ops.rows_unit_norm(W.clone().to(DEV))
+    torch.testing.assert_close(Wn.float().cpu(), ref, **tol)
+    torch.testing.assert_close(Wn.float().norm(dim=1).cpu(), torch.ones(M), rtol=1e-2, atol=1e-2)
+    Gr = torch.randn(M, d, generator=g).to(dtype)
+    refp = Gr.float() - (Gr.float() * Wn.float().cpu()).sum(1, keepdim=True) * Wn.float().cpu()
+    Gp = ops.rows_project_out(Gr.clone().to(DEV), Wn)
+    torch.testing.assert_close(Gp.float().cpu(), refp, **tol)
+    assert float((Gp.float() * Wn.float()).sum(1).abs().max()) < (1e-4 if dtype == torch.float32 else 0.25)
+    # fused into the decoder row pass
+    N, k = 96, 8
+    idx = torch.stack([torch.randperm(M, generator=g)[:k] for _ in range(N)]).to(DEV)
+    v = torch.rand(N, k, generator=g).to(dtype).to(DEV)
+    G = torch.randn(N, d, generator=g).to(dtype).to(DEV)
+    _, acts = ops.decode_fwd(idx, v, Wn, want_acts=True)
+    seg = ops.segments_build(idx, M)
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    p3 = torch.nn.Parameter(Wn.clone())
+    opt3 = Adam([p3], **hp)
+    W2, m2, v2 = Wn.clone(), torch.zeros_like(Wn), torch.zeros_like(Wn)
+    for step in (1, 2):
+        ga = torch.zeros(N, k, device=DEV)
+        gW, _, _ = ops.decode_bwd_rows(seg, acts.view(-1), v, p3.data, G, ga)
+        p3.grad = ops.rows_project_out(gW, p3.data)
+        opt3.step()
+        ga2 = torch.zeros(N, k, device=DEV)
+        ops.decode_bwd_rows(seg, acts.view(-1), v, W2, G, ga2, adam=dict(m=m2, v=v2, step=step, project=True, **hp))
+        assert torch.equal(ga2, ga) and torch.equal(W2, p3.data)
+        assert torch.equal(m2, opt3.state[p3]["exp_avg"]) and torch.equal(v2, opt3.state[p3]["exp_avg_sq"])
+
+
 def test_segments_skewed(ops):
     """One latent active on every token (long segment) + many empty latents."""
     N, k, M, d = 700, 8, 512, 64
