@@ -238,6 +238,18 @@ def main():
             roofline = {"kernel": dominant, "bound": e["bound"], "achieved": e["achieved"],
                         "peak": 2500.0 if e["bound"] == "mfma" else 8000.0, "unit": e["unit"], "frac": e["frac"],
                         "traffic": traffic}
+        # Whole-step roofline of SURVEY.md section 8d (the reference's own cost model, scripts/benchmarks/distributed.py:
+        # 30-38, with this part's peaks), per rank: encoder flops + skip GEMM flops at the MFMA peak, decode forward
+        # (B_dec per pair), decode backward (2 B_dec per pair), encoder sparse backward (B_dec per layer) and dense
+        # Adam (7 * s * P) at the HBM peak.  frac = that time / the measured step.
+        pairs = L * (L + 1) // 2
+        Ntot = tokens_per_step
+        B_dec = es * Ntot * (k / world + 1) * d
+        flops = L * 2.0 * Ntot * d * Ml + pairs * 3 * 2.0 * N * d * d
+        hbm = pairs * 3 * B_dec + L * B_dec + 7.0 * es * P_total
+        roof_s = flops / PEAK_BF16 + hbm / PEAK_HBM
+        step_roofline = {"ms": round(roof_s * 1e3, 3), "frac": round(roof_s / (dt / args.steps), 4),
+                         "tokens_per_s_at_roofline": round(tokens_per_step / roof_s, 1)}
         cpu = None
         if not args.no_cpu_baseline:
             sys.path.insert(0, str(ROOT))
@@ -255,7 +267,7 @@ def main():
                                    f"(BASELINE.json configs[1])",
                        "tokens_per_step": tokens_per_step, "params_per_gpu": P_total, "parallelism": parallelism},
             "fvu_last": round(float(sum(float(v) for v in fv.values()) / len(fv)), 5),
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "step_roofline": step_roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if real_world > 1:
