@@ -50,12 +50,12 @@ SIGNATURES = {
     "clt_decode_bwd_acts_multi": (_i32, [_vp, _i32, _i32, _i32, _i64, _i32, _vp, _i32, _i64, _i32, _vp]),
     "clt_segments_workspace_bytes": (_sz, [_i64, _i64]),
     "clt_segments_build": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "clt_spt_dense": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "clt_spt_dense": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _vp, _sz, _vp]),
     "clt_rows_workspace_bytes": (_sz, [_i64, _i32]),
     "clt_spt_dense_adam": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp,
                                   _f32, _f32, _f32, _f32, _i32, _i64, _vp, _sz, _vp]),
     "clt_decode_bwd_rows": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
-                                   _vp, _vp, _vp]),
+                                   _vp, _vp, _i64, _vp, _sz, _vp]),
     "clt_decode_bwd_rows_adam": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
                                         _i32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _i64, _vp, _sz, _vp]),
     "clt_rows_unit_norm": (_i32, [_vp, _i32, _i64, _i32, _f32, _vp]),

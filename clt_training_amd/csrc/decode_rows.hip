@@ -33,7 +33,8 @@ static int check_rows_args(const char* name, const int32_t* perm, const int32_t*
 extern "C" int clt_decode_bwd_rows(const int32_t* perm, const int32_t* offsets, int64_t M, const float* acts,
                                    const void* v, int v_dtype, const float* post_enc, const float* post_scale,
                                    const void* G, int g_dtype, int d, int k, const void* W, int w_dtype, void* grad_W,
-                                   float* grad_acts, float* g_post, float* g_scale, clt_stream_t stream) {
+                                   float* grad_acts, float* g_post, float* g_scale, int64_t n_entries, void* workspace,
+                                   size_t workspace_bytes, clt_stream_t stream) {
   int ch;
   int rc = check_rows_args("clt_decode_bwd_rows", perm, offsets, M, acts, v, v_dtype, post_scale, G, g_dtype, d, k, W,
                            w_dtype, grad_acts, g_scale, &ch);
@@ -41,7 +42,14 @@ extern "C" int clt_decode_bwd_rows(const int32_t* perm, const int32_t* offsets, 
   CLT_CHECK_ARG(grad_W && aligned16(grad_W), "clt_decode_bwd_rows: grad_W is null or misaligned");
   BwdActs bw = {v, v_dtype, post_enc, post_scale, grad_acts, g_post, g_scale, W};
   hipStream_t st = (hipStream_t)stream;
-  if (g_dtype == CLT_BF16)
+  const bool lds_ok = rows_lds_ok(d, dtype_size(w_dtype), ch, 1);
+  if (lds_ok && g_dtype == CLT_BF16)
+    rc = launch_rows_lds<bf16_t, true, false>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, grad_W, nullptr, AdamRows(),
+                                              bw, n_entries, workspace, workspace_bytes);
+  else if (lds_ok)
+    rc = launch_rows_lds<float, true, false>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, grad_W, nullptr, AdamRows(),
+                                             bw, n_entries, workspace, workspace_bytes);
+  else if (g_dtype == CLT_BF16)
     rc = launch_spt<bf16_t, bf16_t, false, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, grad_W, nullptr, AdamRows(), bw);
   else
     rc = launch_spt<float, float, false, true>(ch, st, perm, offsets, M, acts, nullptr, 0, G, d, k, grad_W, nullptr, AdamRows(), bw);

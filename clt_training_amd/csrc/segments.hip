@@ -118,7 +118,8 @@ extern "C" int clt_segments_build(const int64_t* idx, int64_t n, int64_t M, int6
 
 extern "C" int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_t M, const float* vals,
                              const void* vals_gate, int gate_dtype, const void* dense, int dense_dtype, int d, int k,
-                             void* out, int out_dtype, float* rowsum, clt_stream_t stream) {
+                             void* out, int out_dtype, float* rowsum, int64_t n_entries, void* workspace,
+                             size_t workspace_bytes, clt_stream_t stream) {
   CLT_CHECK_ARG(perm && offsets && vals && dense && out, "clt_spt_dense: null pointer");
   CLT_CHECK_ARG(M > 0 && M < (1ll << 31) && d > 0 && k > 0, "clt_spt_dense: bad sizes");
   CLT_CHECK_ARG(valid_dtype(dense_dtype) && valid_dtype(out_dtype) && (!vals_gate || valid_dtype(gate_dtype)),
@@ -132,7 +133,14 @@ extern "C" int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_
   CLT_UNSUPPORTED(ch > 0, "clt_spt_dense: d=%d too wide", d);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (dense_dtype == CLT_BF16 && out_dtype == CLT_BF16)
+  const bool lds_ok = dense_dtype == out_dtype && rows_lds_ok(d, dtype_size(out_dtype), ch, 0);
+  if (lds_ok && out_dtype == CLT_BF16)
+    rc = launch_rows_lds<bf16_t, false, false>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum,
+                                               AdamRows(), BwdActs(), n_entries, workspace, workspace_bytes);
+  else if (lds_ok)
+    rc = launch_rows_lds<float, false, false>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum,
+                                              AdamRows(), BwdActs(), n_entries, workspace, workspace_bytes);
+  else if (dense_dtype == CLT_BF16 && out_dtype == CLT_BF16)
     rc = launch_spt<bf16_t, bf16_t>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);
   else if (dense_dtype == CLT_BF16 && out_dtype == CLT_F32)
     rc = launch_spt<bf16_t, float>(ch, st, perm, offsets, M, vals, vals_gate, gate_dtype, dense, d, k, out, rowsum);

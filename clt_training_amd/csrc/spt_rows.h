@@ -541,7 +541,9 @@ __global__ __launch_bounds__(64) void rows_long_kernel(const int32_t* __restrict
   }
 }
 
-template <typename T, int CH, int U, bool BWD>
+// ADAM = false: the plain-gradient form (clt_spt_dense, clt_decode_bwd_rows): `out` receives the gradient row, only
+// the table row bw.W is staged (BWD) or nothing at all, and the long-segment pre-reduction is shared.
+template <typename T, int CH, int U, bool BWD, bool ADAM = true>
 __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds_kernel(
     const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets, int64_t M, const float* __restrict__ vals,
     const void* __restrict__ gate, int gate_dtype, const T* __restrict__ dense, int d, int k, T* __restrict__ out,
@@ -553,7 +555,8 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds
   if (row >= M) return;
   const int nchunks = d / E;
   const int rowbytes = d * (int)sizeof(T);
-  char* my_lds = rows_lds + (size_t)wave * 3 * rowbytes;
+  constexpr int NARR = ADAM ? 3 : (BWD ? 1 : 0);  // staged arrays per row
+  char* my_lds = rows_lds + (size_t)wave * NARR * rowbytes;
   // (wave-uniform, but hipcc cannot know: readfirstlane puts it in an SGPR for the m0 moves)
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void_ptr)my_lds);
   const int my_off = lane < 2 ? offsets[row + lane] : 0;
@@ -563,9 +566,13 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds
     const int ch = lane + 64 * c;
     if (ch < nchunks) {
       const uint32_t dst = lds0 + (uint32_t)(c * 1024);
-      rows_dma16(out + roff + ch * E, dst);
-      rows_dma16(reinterpret_cast<const T*>(ad.m) + roff + ch * E, dst + rowbytes);
-      rows_dma16(reinterpret_cast<const T*>(ad.v) + roff + ch * E, dst + 2 * rowbytes);
+      if constexpr (ADAM) {
+        rows_dma16(out + roff + ch * E, dst);
+        rows_dma16(reinterpret_cast<const T*>(ad.m) + roff + ch * E, dst + rowbytes);
+        rows_dma16(reinterpret_cast<const T*>(ad.v) + roff + ch * E, dst + 2 * rowbytes);
+      } else if constexpr (BWD) {
+        rows_dma16(reinterpret_cast<const T*>(bw.W) + roff + ch * E, dst);
+      }
     }
   }
   const int beg = readlane_i(my_off, 0), end = readlane_i(my_off, 1);
@@ -682,41 +689,49 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds
     }
   }
 
-  // ---- the row is complete: optimizer update out of LDS
-  if (!staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  float dot = 0.f;
-  if (ad.project) {  // wave-uniform
+  // ---- the row is complete: optimizer update out of LDS, or the gradient row itself
+  if (NARR > 0 && !staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also: no DMA may outlive the wave)
+  if constexpr (ADAM) {
+    float dot = 0.f;
+    if (ad.project) {  // wave-uniform
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      if (lane + 64 * c < nchunks) {
-        float wv[E];
-        lds_chunk(0, c, wv);
+      for (int c = 0; c < CH; ++c) {
+        if (lane + 64 * c < nchunks) {
+          float wv[E];
+          lds_chunk(0, c, wv);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const float g = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
-          dot = fmaf(g, wv[e], dot);
+          for (int e = 0; e < E; ++e) {
+            const float g = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+            dot = fmaf(g, wv[e], dot);
+          }
         }
       }
+      dot = wave_sum_dpp(dot);
     }
-    dot = wave_sum_dpp(dot);
-  }
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int ch = lane + 64 * c;
-    if (ch < nchunks) {
-      float pf[E], mf[E], vf[E];
-      lds_chunk(0, c, pf);
-      lds_chunk(1, c, mf);
-      lds_chunk(2, c, vf);
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) {
+        float pf[E], mf[E], vf[E];
+        lds_chunk(0, c, pf);
+        lds_chunk(1, c, mf);
+        lds_chunk(2, c, vf);
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        float g = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
-        if (ad.project) g = project_elem<sizeof(T) == 2>(g, pf[e], dot);
-        adam_update(pf[e], mf[e], vf[e], g, ad.step_size, ad.b1, ad.b2, ad.inv_sqrt_bc2, ad.eps);
+        for (int e = 0; e < E; ++e) {
+          float g = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(acc[c][e])) : acc[c][e];
+          if (ad.project) g = project_elem<sizeof(T) == 2>(g, pf[e], dot);
+          adam_update(pf[e], mf[e], vf[e], g, ad.step_size, ad.b1, ad.b2, ad.inv_sqrt_bc2, ad.eps);
+        }
+        store_row_chunk<T, E>(out + roff + ch * E, pf);
+        store_row_chunk<T, E>(reinterpret_cast<T*>(ad.m) + roff + ch * E, mf);
+        store_row_chunk<T, E>(reinterpret_cast<T*>(ad.v) + roff + ch * E, vf);
       }
-      store_row_chunk<T, E>(out + roff + ch * E, pf);
-      store_row_chunk<T, E>(reinterpret_cast<T*>(ad.m) + roff + ch * E, mf);
-      store_row_chunk<T, E>(reinterpret_cast<T*>(ad.v) + roff + ch * E, vf);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) store_row_chunk<T, E>(out + roff + ch * E, acc[c]);  // zeros for an empty row
     }
   }
   if (lane == 0) {
@@ -729,18 +744,19 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds
 }
 
 // The LDS-staged kernel serves rows of up to 10 KiB (2 waves * 3 arrays * row <= 64 KiB of LDS) and 8 chunks per lane.
-static inline bool rows_lds_ok(int d, size_t elem, int ch) {
+static inline bool rows_lds_ok(int d, size_t elem, int ch, int narr = 3) {
   static const bool off = getenv("CLT_ROWS_LDS") && atoi(getenv("CLT_ROWS_LDS")) == 0;  // A/B switch (tests, tuning)
-  return !off && ch <= 8 && 2 * 3 * (size_t)d * elem <= 65536;
+  return !off && ch <= 8 && 2 * (size_t)narr * (size_t)d * elem <= 65536;
 }
 
-template <typename T, bool BWD>
+template <typename T, bool BWD, bool ADAM = true>
 static int launch_rows_lds(int ch, hipStream_t st, const int32_t* perm, const int32_t* offsets, int64_t M,
                            const float* vals, const void* gate, int gate_dtype, const void* dense, int d, int k, void* out,
                            float* rowsum, AdamRows ad, BwdActs bw, int64_t n_entries, void* workspace,
                            size_t workspace_bytes) {
   const dim3 grid((unsigned)((M + 1) / 2));
-  const size_t lds = 2 * 3 * (size_t)d * sizeof(T);
+  const size_t lds = 2 * (size_t)(ADAM ? 3 : (BWD ? 1 : 0)) * (size_t)d * sizeof(T);
+  const void* table = ADAM ? out : bw.W;  // the rows the decoder backward dots against (the long-row helper reads them)
   LongRows lr = {nullptr, d + 4};
   const bool longs = workspace != nullptr && n_entries > ROWS_LT && workspace_bytes >= rows_long_workspace_bytes(n_entries, d);
   const dim3 lgrid((unsigned)((n_entries + ROWS_LT - 1) / ROWS_LT));
@@ -749,9 +765,9 @@ static int launch_rows_lds(int ch, hipStream_t st, const int32_t* perm, const in
   do {                                                                                                                \
     if (longs)                                                                                                        \
       hipLaunchKernelGGL((rows_long_kernel<T, CH, U, BWD>), lgrid, dim3(64), 0, st, perm, offsets, M, vals, gate,     \
-                         gate_dtype, (const T*)dense, d, k, (const T*)out, bw, lr);                                   \
-    hipLaunchKernelGGL((rows_lds_kernel<T, CH, U, BWD>), grid, dim3(128), lds, st, perm, offsets, M, vals, gate,      \
-                       gate_dtype, (const T*)dense, d, k, (T*)out, rowsum, ad, bw, lr);                               \
+                         gate_dtype, (const T*)dense, d, k, (const T*)table, bw, lr);                                 \
+    hipLaunchKernelGGL((rows_lds_kernel<T, CH, U, BWD, ADAM>), grid, dim3(128), lds, st, perm, offsets, M, vals,      \
+                       gate, gate_dtype, (const T*)dense, d, k, (T*)out, rowsum, ad, bw, lr);                         \
   } while (0)
   switch (ch) {
     case 1: LAUNCH(1, 8); break;

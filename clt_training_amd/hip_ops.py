@@ -293,9 +293,11 @@ def spt_dense(seg: Segments, vals: Tensor, dense: Tensor, *, gate: Optional[Tens
         out = torch.empty(seg.M, d, dtype=out_dtype, device=dense.device)
     rowsum = torch.empty(seg.M, dtype=torch.float32, device=dense.device) if want_rowsum else None
     gate = None if gate is None else _c(gate)
+    n = seg.perm.numel()
+    ws = workspace(dense.device, _lib.load().clt_rows_workspace_bytes(n, d), "rows")  # long-row partials
     _call("clt_spt_dense", _ptr(seg.perm), _ptr(seg.offsets), seg.M, _ptr(vals), _ptr(gate),
-                                    _dt(gate) if gate is not None else 0, _ptr(dense), _dt(dense), d, seg.k, _ptr(out),
-                                    _dt(out), _ptr(rowsum), _stream(dense))
+          _dt(gate) if gate is not None else 0, _ptr(dense), _dt(dense), d, seg.k, _ptr(out), _dt(out), _ptr(rowsum), n,
+          _ptr(ws), ws.numel(), _stream(dense))
     return (out, rowsum) if want_rowsum else out
 
 
@@ -336,16 +338,16 @@ def decode_bwd_rows(seg: Segments, acts: Tensor, v: Tensor, W: Tensor, G: Tensor
     g_scale = torch.empty(M, dtype=torch.float32, device=W.device) if post_scale is not None else None
     head = (_ptr(seg.perm), _ptr(seg.offsets), M, _ptr(acts), _ptr(v), _dt(v), _ptr(post_enc), _ptr(post_scale), _ptr(G),
             _dt(G), d, seg.k)
+    n = seg.perm.numel()
+    ws = workspace(W.device, _lib.load().clt_rows_workspace_bytes(n, d), "rows")  # long-row partials
     if adam is None:
         gW = torch.empty(M, d, dtype=W.dtype, device=W.device)
         _call("clt_decode_bwd_rows", *head, _ptr(W), _dt(W), _ptr(gW), _ptr(grad_acts), _ptr(g_post), _ptr(g_scale),
-              _stream(W))
+              n, _ptr(ws), ws.numel(), _stream(W))
         return gW, g_post, g_scale
     m_, v_ = adam["m"], adam["v"]
     assert m_.dtype == W.dtype and v_.dtype == W.dtype and m_.shape == W.shape and v_.shape == W.shape
     assert m_.is_contiguous() and v_.is_contiguous()
-    n = seg.perm.numel()
-    ws = workspace(W.device, _lib.load().clt_rows_workspace_bytes(n, d), "rows")  # long-row partials
     _call("clt_decode_bwd_rows_adam", *head, _ptr(W), _ptr(m_), _ptr(v_), _dt(W), _ptr(grad_acts), _ptr(g_post),
           _ptr(g_scale), float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]), float(adam["eps"]),
           int(adam["step"]), int(bool(adam.get("project", False))), n, _ptr(ws), ws.numel(), _stream(W))

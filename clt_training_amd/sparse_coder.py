@@ -67,6 +67,20 @@ class FusedDecode(torch.autograd.Function):
         need_acts, _, need_pe, need_ps, need_W, need_b, _ = ctx.needs_input_grad
         g_acts = g_pe = g_ps = g_W = g_b = None
         seg = None
+        if need_W and need_acts and G.dtype == W_dec.dtype and W_dec.is_contiguous():
+            # ONE row pass (clt_decode_bwd_rows): weight gradient, gradient wrt the activations and the post-encoder
+            # sums, without gathering the k decoder rows per token a second time; long segments are load-balanced
+            seg = ctx.holder.get(indices, W_dec.shape[0])
+            ga = torch.zeros(indices.shape, dtype=torch.float32, device=G.device)
+            g_W, g_pe, g_ps = ops.decode_bwd_rows(seg, acts.view(-1), latent_acts, W_dec, G, ga, post_enc=post_enc,
+                                                  post_scale=post_scale,
+                                                  want_g_post=bool(need_pe and post_enc is not None))
+            g_acts = ga if ga.dtype == latent_acts.dtype else ga.to(latent_acts.dtype)
+            if not need_ps:
+                g_ps = None
+            if ctx.has_bias and need_b:
+                g_b = G.sum(0, dtype=torch.float32)
+            return g_acts, None, g_pe, g_ps, g_W, g_b, None
         if need_acts or need_pe or need_ps:
             ga, e_post, e_scale = ops.decode_bwd_acts(indices, latent_acts, W_dec, G, post_enc=post_enc,
                                                       post_scale=post_scale,

@@ -159,10 +159,12 @@ int clt_segments_build(const int64_t* idx, int64_t n_entries, int64_t M, int64_t
  *               grad_b of fused_encoder.py:140-143)
  * vals [N*k] fp32; vals_gate [N*k] (`gate_dtype`) or NULL: when given, vals[e] is multiplied by
  * (vals_gate[e] > 0) -- the (values > 0) mask of fused_encoder.py:97; dense [N,d] `dense_dtype`;
- * out [M,d] `out_dtype`.  Atomic-free and bitwise reproducible.                                 */
+ * out [M,d] `out_dtype`.  Atomic-free and bitwise reproducible.  n_entries / workspace: the optional long-segment
+ * pre-reduction described at clt_spt_dense_adam (workspace NULL, or dense_dtype != out_dtype: every row is walked
+ * by one wave).                                                                                  */
 int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_t M, const float* vals, const void* vals_gate,
                   int gate_dtype, const void* dense, int dense_dtype, int d, int k, void* out, int out_dtype,
-                  float* rowsum, clt_stream_t stream);
+                  float* rowsum, int64_t n_entries, void* workspace, size_t workspace_bytes, clt_stream_t stream);
 
 /* clt_spt_dense with the optimizer step applied to each finished row, for steps in which the gradient has no
  * other consumer (grad_acc_steps == 1, no clipping): the fusion of the dense grad-W write of xformers.py:179-231 /
@@ -200,7 +202,8 @@ int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, int64_t M, c
 int clt_decode_bwd_rows(const int32_t* perm, const int32_t* offsets, int64_t M, const float* acts, const void* v,
                         int v_dtype, const float* post_enc, const float* post_scale, const void* G, int g_dtype, int d,
                         int k, const void* W, int w_dtype, void* grad_W, float* grad_acts, float* g_post,
-                        float* g_scale, clt_stream_t stream);
+                        float* g_scale, int64_t n_entries, void* workspace, size_t workspace_bytes,
+                        clt_stream_t stream);
 int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offsets, int64_t M, const float* acts, const void* v,
                              int v_dtype, const float* post_enc, const float* post_scale, const void* G, int g_dtype,
                              int d, int k, void* W, void* exp_avg, void* exp_avg_sq, int w_dtype, float* grad_acts,

@@ -177,10 +177,15 @@ def test_decode_bwd_rows_equals_separate_kernels(ops, dtype, N, d, M, k, shard, 
     # one row pass
     ga2 = acc0.clone()
     gW2, gp2, gs2 = ops.decode_bwd_rows(seg, acts.view(-1), v, W, G, ga2, post_enc=pe, post_scale=ps, want_g_post=True)
+    off = seg.offsets.long()
+    short = (off[1:] - off[:-1]) <= 512  # longer rows are pre-reduced in blocks: another fp32 summation order
     assert torch.equal(gW2, gW1)
     assert torch.equal(ga2, ga1)
-    assert torch.equal(gp2, gp1)
-    assert (gs2 is None and gs1 is None) or torch.equal(gs2, gs1)
+    assert torch.equal(gp2[short], gp1[short])
+    torch.testing.assert_close(gp2, gp1, rtol=1e-4, atol=1e-4)
+    assert (gs2 is None and gs1 is None) or torch.equal(gs2[short], gs1[short])
+    if gs2 is not None:
+        torch.testing.assert_close(gs2, gs1, rtol=1e-4, atol=1e-4)
     # against the oracle as well
     own = ((idx >= lo) & (idx < hi)).cpu()
     ga_ref = (W.float().cpu()[(idx.cpu() - lo).clamp(0, hi - lo - 1)] * G.float().cpu().unsqueeze(1)).sum(-1) * own
@@ -193,8 +198,6 @@ def test_decode_bwd_rows_equals_separate_kernels(ops, dtype, N, d, M, k, shard, 
     from clt_training_amd.adam import Adam
     p3 = torch.nn.Parameter(W.clone())
     opt3 = Adam([p3], **hp)
-    off = seg.offsets.long()
-    short = (off[1:] - off[:-1]) <= 512  # longer rows are pre-reduced in blocks: another fp32 summation order
     for step in (1, 2):
         ops.spt_dense_adam(seg, acts.view(-1), G, W1, m1, v1, step=step, **hp)
         p3.grad = gW1.clone()
