@@ -47,6 +47,16 @@ class Adam(torch.optim.Optimizer):
         return dict(m=st["exp_avg"], v=st["exp_avg_sq"], lr=float(g["lr"]), betas=g["betas"], eps=g["eps"],
                     step=self._step + 1)
 
+    def fused_rows_by_ptr(self, ptr: int):
+        """fused_rows for the parameter whose storage starts at ``ptr`` (autograd Functions see saved tensors, not the
+        Parameter objects).  Parameters that already hold a .grad are not eligible."""
+        if not hasattr(self, "_by_ptr"):
+            self._by_ptr = {q.data_ptr(): q for g in self.param_groups for q in g["params"]}
+        p = self._by_ptr.get(ptr)
+        if p is None or p.grad is not None:
+            return None
+        return self.fused_rows(p)
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None

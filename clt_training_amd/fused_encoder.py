@@ -8,6 +8,7 @@ from typing import Literal, NamedTuple
 import torch
 from torch import Tensor
 
+from . import fused_state
 from . import hip_ops as ops
 from .utils import SegmentsHolder, holder_of
 
@@ -27,6 +28,7 @@ def _compute_dtype(input: Tensor, weight: Tensor):
 class FusedEncoder(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, weight, bias, values, indices, activation=None):
+        fused_state.note_use(weight)
         ctx.save_for_backward(input, weight, bias, values, indices)
         ctx.k = values.shape[-1]
         ctx.activation = activation
@@ -48,8 +50,14 @@ class FusedEncoder(torch.autograd.Function):
             seg = ctx.holder.get(indices, M)
             # grad_W[idx, :] += gv * x (fused_encoder.py:150-155); grad_b[idx] += gv (:140-143)
             x = input if input.dtype in (torch.float32, torch.bfloat16) else input.float()
-            gw, gb = ops.spt_dense(seg, gv.view(-1), x, gate=values.contiguous().view(-1), out_dtype=weight.dtype,
-                                   want_rowsum=True)
+            h = fused_state.fused_for(weight) if (ctx.needs_input_grad[1] and x.dtype == weight.dtype) else None
+            if h is not None:  # the optimizer update happens inside the gradient kernel: no grad_weight
+                gw = None
+                gb = ops.spt_dense_adam(seg, gv.view(-1), x, weight.data, h["m"], h["v"], lr=h["lr"], betas=h["betas"],
+                                        eps=h["eps"], step=h["step"], gate=values.contiguous().view(-1), want_rowsum=True)
+            else:
+                gw, gb = ops.spt_dense(seg, gv.view(-1), x, gate=values.contiguous().view(-1), out_dtype=weight.dtype,
+                                       want_rowsum=True)
             if ctx.needs_input_grad[1]:
                 grad_weight = gw
             if need_b:

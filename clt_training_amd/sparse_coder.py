@@ -18,6 +18,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
+from . import fused_state
 from . import hip_ops as ops
 from .config import SparseCoderConfig
 from .fused_encoder import EncoderOutput, fused_encoder
@@ -54,6 +55,7 @@ class FusedDecode(torch.autograd.Function):
     def forward(ctx, latent_acts, indices, post_enc, post_scale, W_dec, b_dec, round_acts: bool):
         out, acts = ops.decode_fwd(indices, latent_acts, W_dec, post_enc=post_enc, post_scale=post_scale, bias=b_dec,
                                    round_acts=round_acts, want_acts=True)
+        fused_state.note_use(W_dec)
         ctx.save_for_backward(latent_acts, indices, post_enc, post_scale, W_dec, acts)
         ctx.holder = holder_of(indices)
         ctx.has_bias = b_dec is not None
@@ -72,9 +74,10 @@ class FusedDecode(torch.autograd.Function):
             # sums, without gathering the k decoder rows per token a second time; long segments are load-balanced
             seg = ctx.holder.get(indices, W_dec.shape[0])
             ga = torch.zeros(indices.shape, dtype=torch.float32, device=G.device)
-            g_W, g_pe, g_ps = ops.decode_bwd_rows(seg, acts.view(-1), latent_acts, W_dec, G, ga, post_enc=post_enc,
+            g_W, g_pe, g_ps = ops.decode_bwd_rows(seg, acts.view(-1), latent_acts, W_dec.data, G, ga, post_enc=post_enc,
                                                   post_scale=post_scale,
-                                                  want_g_post=bool(need_pe and post_enc is not None))
+                                                  want_g_post=bool(need_pe and post_enc is not None),
+                                                  adam=fused_state.fused_for(W_dec))  # fused: g_W is None
             g_acts = ga if ga.dtype == latent_acts.dtype else ga.to(latent_acts.dtype)
             if not need_ps:
                 g_ps = None
@@ -437,7 +440,9 @@ class SparseCoder(nn.Module):
     @torch.no_grad()
     def remove_gradient_parallel_to_decoder_directions(self):
         for W_dec in self.W_decs if hasattr(self, "W_decs") else (self.W_dec,):
-            assert W_dec is not None and W_dec.grad is not None
+            assert W_dec is not None
+            if W_dec.grad is None:
+                continue  # projected and consumed inside the row pass (fused_state)
             if W_dec.is_cuda and W_dec.grad.dtype == W_dec.dtype:  # one HIP pass (clt_rows_project_out)
                 if not W_dec.grad.is_contiguous():
                     W_dec.grad = W_dec.grad.contiguous()

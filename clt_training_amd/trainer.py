@@ -9,12 +9,14 @@ step-0 data-dependent init (:547-592), the encode/decode/backward/restore order 
 ``{hookpoint: (inputs[N, d], outputs[N, d])}`` (BASELINE.json north_star)."""
 from __future__ import annotations
 
+import os
 from dataclasses import replace
 from typing import Callable, Iterable, Optional
 
 import torch
 from torch import Tensor
 
+from . import fused_state
 from .adam import Adam
 from .config import TrainConfig
 from .runner import CrossLayerRunner
@@ -90,6 +92,13 @@ class Trainer:
         adam = Adam(pgs, betas=(cfg.b1, cfg.b2))
         self.optimizers = [adam]
         self.lr_schedulers = [WarmupLinearSchedule(adam, cfg.lr_warmup_steps, num_batches)]
+        # Row gradients of the [M, d] matrices go straight into the Adam update inside the gradient kernels when each
+        # optimizer step sees one micro-step (fused_state): no dense .grad, no second pass over the tables.
+        self._fused = (cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and not os.environ.get("CLT_NO_FUSED_ADAM"))
+        if self._fused:
+            for sae in self.saes.values():
+                if sae.cfg.normalize_decoder and not cfg.sae.transcode:
+                    fused_state.set_project(sae.W_dec)
 
         self.global_step = 0
         self.num_tokens_since_fired = {
@@ -143,6 +152,8 @@ class Trainer:
     def step(self, batch: dict):
         """One pass over all hookpoints in network order + optimizer step (trainer.py:684-816)."""
         acc_steps = self.cfg.grad_acc_steps * self.cfg.micro_acc_steps
+        fused_state.ACTIVE = self.optimizers[0] if self._fused else None
+        fused_state.begin_step()
         self.runner.reset()
         loss_mask = batch.get("loss_mask")
         n_tok = 0

@@ -236,3 +236,49 @@ def test_trainer_three_steps_vs_oracle(fp32_exact):
             torch.testing.assert_close(sae.b_decs[i].detach().cpu(), layers[l].b_decs[i], rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(sae.W_skips[i].detach().cpu(), layers[l].W_skips[i], rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(sae.post_enc_scales[i].detach().cpu(), layers[l].post_enc_scales[i], rtol=1e-4, atol=1e-5)
+
+
+def test_trainer_fused_adam_equals_grad_then_adam(monkeypatch):
+    """The drop-in Trainer (SparseCoder / CrossLayerRunner / autograd) with the row gradients consumed by the Adam update
+    inside the gradient kernels (fused_state) against the same steps through .grad -> Adam.step: every parameter bit
+    for bit after 3 bf16 steps, for a CLT and for a unit-norm SAE (projection inside the row pass)."""
+    from clt_training_amd import SparseCoderConfig, TrainConfig, Trainer
+
+    for kw, L, cross in ((dict(transcode=True, skip_connection=True, post_encoder_scale=True), 3, 3),
+                         (dict(transcode=False, normalize_decoder=True), 1, 0)):
+        d, N, k = 64, 512, 8
+        hooks = [f"h.{i}" for i in range(L)]
+        g = torch.Generator().manual_seed(3)
+        batches = []
+        for s_ in range(3):
+            b = {}
+            for h in hooks:
+                x = torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)
+                b[h] = (x.bfloat16().to(DEV), (0.5 * x + 0.5 * torch.randn(N, d, generator=g)).bfloat16().to(DEV))
+            b["loss_mask"] = (torch.rand(N, generator=g) > 0.1).to(DEV)
+            batches.append(b)
+
+        def run(fused):
+            if fused:
+                monkeypatch.delenv("CLT_NO_FUSED_ADAM", raising=False)
+            else:
+                monkeypatch.setenv("CLT_NO_FUSED_ADAM", "1")
+            torch.manual_seed(0)
+            cfg = TrainConfig(sae=SparseCoderConfig(dtype="bfloat16", expansion_factor=32, k=k, **kw), hookpoints=list(hooks),
+                              cross_layer=cross, optimizer="adam", lr=1e-3, lr_warmup_steps=1, log_to_wandb=False)
+            tr = Trainer(cfg, batches, device=DEV, num_batches=10)
+            assert tr._fused == fused
+            with torch.no_grad():
+                gg = torch.Generator(device=DEV).manual_seed(1)
+                for sae in tr.saes.values():
+                    for n, p in sae.named_parameters():
+                        if n.startswith("W_dec") and kw["transcode"]:
+                            p.copy_((0.05 * torch.randn(p.shape, generator=gg, device=DEV)).to(p.dtype))
+            fv = [{h: float(v) for h, v in tr.step(b).items()} for b in batches]
+            return fv, {f"{h}.{n}": p.detach().clone() for h, sae in tr.saes.items() for n, p in sae.named_parameters()}
+
+        fv_a, pa = run(True)
+        fv_b, pb = run(False)
+        for n in pa:
+            assert torch.equal(pa[n], pb[n]), n
+        assert fv_a == fv_b
