@@ -179,7 +179,7 @@ def main():
                     p.copy_(0.01 * torch.randn(p.shape, generator=g, device=device))
     P_total = sum(p.numel() for sae in trainer.saes.values() for p in sae.parameters())
     # parameters that still go through clt_adam_step: everything but the [M, d] matrices when their update is fused
-    fused = getattr(getattr(trainer, "engine", None), "fused_opt", None) is not None
+    fused = getattr(getattr(trainer, "engine", None), "fused_opt", None) is not None or getattr(trainer, "_fused", False)
     P_adam = sum(p.numel() for sae in trainer.saes.values() for p in sae.parameters() if not (fused and p.dim() == 2 and p.shape[0] > d))
 
     real_world = int(os.environ.get("WORLD_SIZE", "1"))
