@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--path", default="engine", choices=["engine", "autograd"],
                     help="engine: explicit CLTEngine (also the multi-GPU path); autograd: SparseCoder/CrossLayerRunner")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sae", action="store_true",
+                    help="plain SAE per hookpoint (no transcoding, no skip, unit-norm decoder): BASELINE configs[3] shape "
+                         "with --layers 1 --d-model 4096 --expansion 32 --k 192; a secondary data point, not the metric")
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="rehearse rank 0's compute of a W-rank run on one GPU (collectives are local stand-ins; "
                          "NOT a measurement of the metric: the line is marked 'simulated')")
@@ -148,9 +151,9 @@ def main():
     N = args.tokens
     hooks = [f"h.{i}.mlp" for i in range(L)]
     sae_cfg = SparseCoderConfig(dtype=args.dtype if args.dtype == "bfloat16" else "none", expansion_factor=args.expansion,
-                                k=k, transcode=True, skip_connection=True)
-    cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=L, optimizer="adam", lr=2e-4, lr_warmup_steps=50,
-                      log_to_wandb=False)
+                                k=k, transcode=not args.sae, skip_connection=not args.sae)
+    cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=0 if args.sae else L, optimizer="adam", lr=2e-4,
+                      lr_warmup_steps=50, log_to_wandb=False)
     act_dtype = torch.bfloat16 if args.dtype == "bfloat16" else torch.float32
     es = 2 if args.dtype == "bfloat16" else 4
 
@@ -214,7 +217,7 @@ def main():
         kernels = {}
         dominant, dom_ms = None, -1.0
         for name, (cnt, ms) in prof.summary().items():
-            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_adam, world, (L + 1) / 2)
+            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_adam, world, 1.0 if args.sae else (L + 1) / 2)
             ent = {"launches_per_step": cnt / args.steps, "mean_ms": round(ms, 4),
                    "ms_per_step": round(ms * cnt / args.steps, 3)}
             if amount is not None:
@@ -242,7 +245,7 @@ def main():
         # 30-38, with this part's peaks), per rank: encoder flops + skip GEMM flops at the MFMA peak, decode forward
         # (B_dec per pair), decode backward (2 B_dec per pair), encoder sparse backward (B_dec per layer) and dense
         # Adam (7 * s * P) at the HBM peak.  frac = that time / the measured step.
-        pairs = L * (L + 1) // 2
+        pairs = L if args.sae else L * (L + 1) // 2
         Ntot = tokens_per_step
         B_dec = es * Ntot * (k / world + 1) * d
         flops = L * 2.0 * Ntot * d * Ml + pairs * 3 * 2.0 * N * d * d

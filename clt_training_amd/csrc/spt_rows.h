@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64) void rows_long_kernel(const int32_t* __restrict
 // ADAM = false: the plain-gradient form (clt_spt_dense, clt_decode_bwd_rows): `out` receives the gradient row, only
 // the table row bw.W is staged (BWD) or nothing at all, and the long-segment pre-reduction is shared.
 template <typename T, int CH, int U, bool BWD, bool ADAM = true>
-__global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 2 : 1)) void rows_lds_kernel(
+__global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds_kernel(
     const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets, int64_t M, const float* __restrict__ vals,
     const void* __restrict__ gate, int gate_dtype, const T* __restrict__ dense, int d, int k, T* __restrict__ out,
     float* __restrict__ rowsum, const AdamRows ad, const BwdActs bw, const LongRows lr) {
@@ -772,7 +772,7 @@ static int launch_rows_lds(int ch, hipStream_t st, const int32_t* perm, const in
   switch (ch) {
     case 1: LAUNCH(1, 8); break;
     case 2: LAUNCH(2, 4); break;
-    case 4: LAUNCH(4, 4); break;
+    case 4: LAUNCH(4, 2); break;  // 3 waves per SIMD (<= 168 VGPRs) beat 4 gathers in flight at d = 2048
     case 8: LAUNCH(8, 2); break;
     default: return CLT_ERR_UNSUPPORTED;
   }

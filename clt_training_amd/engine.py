@@ -529,11 +529,19 @@ class CLTEngine:
             st.slot += 1
             if st.slot >= li.n_slots:
                 if not li.cfg.transcode:
-                    # SAE: the encoder input is xn - b_dec (sparse_coder.py:637-638): b_dec also gets -sum_n grad_x
-                    # (before W_enc's rows may be updated in place by the fused optimizer step below)
-                    gated = st.gv * (st.v > 0)
-                    gx = ops.decode_fwd(st.idx, gated, li.W_enc, lat_begin=li.lat_begin, out_dtype=torch.float32)
-                    self._acc_grad(li.b_decs[0], -gx.sum(0, dtype=torch.float32))
+                    # SAE: the encoder input is xn - b_dec (sparse_coder.py:637-638), so b_dec also gets -sum_n grad_x.
+                    # grad_x[n,:] = sum_j gv[n,j] W_enc[idx[n,j],:] (fused_encoder.py:100-105) is never formed: its
+                    # column sum is  sum_r (sum of the gated gv over latent r's segment) * W_enc[r,:] = grad_b_enc @ W_enc,
+                    # one pass over W_enc instead of a gather of k rows per token (before W_enc's rows are updated in
+                    # place by the fused optimizer step below).  bf16 tables: the fp32 vector goes in as hi + lo parts.
+                    gbe, _ = ops.segment_sum(st.seg, (st.gv * (st.v > 0)).view(-1))
+                    if li.W_enc.dtype == torch.float32:
+                        sx = gbe.unsqueeze(0) @ li.W_enc
+                    else:
+                        hi = gbe.to(li.W_enc.dtype)
+                        lo = (gbe - hi.float()).to(li.W_enc.dtype)
+                        sx = (torch.stack([hi, lo]) @ li.W_enc).float().sum(0, keepdim=True)
+                    self._acc_grad(li.b_decs[0], -sx.view(-1).float())
                 gb = self._grad_rows(li.W_enc, st.seg, st.gv.view(-1), st.x_enc, acc_steps,
                                      gate=st.v.contiguous().view(-1), want_rowsum=True)
                 self._acc_grad(li.b_enc, gb.to(li.b_enc.dtype))
