@@ -9,7 +9,9 @@ import ctypes as C
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libcltmi355.so"
+import os
+
+LIB_PATH = Path(os.environ.get("CLT_LIB", HERE / "libcltmi355.so"))  # (CLT_LIB: A/B builds while tuning)
 
 CLT_F32, CLT_BF16 = 0, 1
 CLT_DECODE_ACCUMULATE, CLT_DECODE_ROUND_ACTS = 1, 2
