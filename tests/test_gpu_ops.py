@@ -352,6 +352,38 @@ def test_sae_row_extras(ops, dtype, M, d):
         assert torch.equal(m2, opt3.state[p3]["exp_avg"]) and torch.equal(v2, opt3.state[p3]["exp_avg_sq"])
 
 
+def test_row_pass_and_fan_out_at_full_c2_size(ops):
+    """BASELINE configs[1] layer size (N=8192, M=98304, d=768, k=32, bf16) through size-independent properties:
+    scaling the bag weights / the loss gradient by 2 scales the outputs by exactly 2 (power-of-two scaling commutes with
+    every rounding), the per-latent sums of grad_acts equal those of the per-token kernel, two shards' partial
+    decodes add up to the unsharded one, and the segments are a permutation sorted by latent."""
+    N, M, d, k = 8192, 98304, 768, 32
+    g = torch.Generator(device=DEV).manual_seed(9)
+    W = (torch.randn(M, d, generator=g, device=DEV) / math.sqrt(d)).bfloat16()
+    idx = torch.stack([torch.randperm(M, generator=g, device=DEV)[:k] for _ in range(256)]).repeat(N // 256, 1)
+    idx = (idx + torch.arange(N, device=DEV)[:, None] * 7919) % M  # distinct within a row, different per token
+    v = torch.rand(N, k, generator=g, device=DEV).bfloat16()
+    G = torch.randn(N, d, generator=g, device=DEV).bfloat16()
+    src = dict(idx=idx, v=v, W=W)
+    y1, (a1,) = ops.decode_fwd_multi([src], want_acts=True, out_dtype=torch.float32)
+    y2 = ops.decode_fwd_multi([dict(src, v=(v.float() * 2).bfloat16())], out_dtype=torch.float32)
+    assert torch.equal(y2, 2 * y1)
+    half = M // 2
+    parts = [ops.decode_fwd_multi([dict(idx=idx, v=v, W=W[lo:lo + half], lat_begin=lo)], out_dtype=torch.float32)
+             for lo in (0, half)]
+    torch.testing.assert_close(parts[0] + parts[1], y1, rtol=1e-5, atol=1e-5)
+    seg = ops.segments_build(idx, M)
+    keys = idx.reshape(-1)[seg.perm.long()]
+    assert bool((keys[1:] >= keys[:-1]).all()) and int(seg.offsets[-1]) == N * k
+    assert torch.equal(torch.sort(seg.perm.long()).values, torch.arange(N * k, device=DEV))
+    ga1, ga2 = torch.zeros(N, k, device=DEV), torch.zeros(N, k, device=DEV)
+    gW1, _, _ = ops.decode_bwd_rows(seg, a1.view(-1), v, W, G, ga1)
+    gW2, _, _ = ops.decode_bwd_rows(seg, (2 * a1).view(-1), v, W, (G.float() * 2).bfloat16(), ga2)
+    assert torch.equal(gW2.float(), 4 * gW1.float()) and torch.equal(ga2, 2 * ga1)
+    ga_tok, _, _ = ops.decode_bwd_acts(idx, v, W, G)
+    assert torch.equal(ga_tok, ga1)
+
+
 def test_segments_skewed(ops):
     """One latent active on every token (long segment) + many empty latents."""
     N, k, M, d = 700, 8, 512, 64
