@@ -142,7 +142,7 @@ class Trainer:
             inputs, sparse_coder=raw,
             dead_mask=self.num_tokens_since_fired[name] > self.cfg.dead_feature_threshold)
         out = self.runner.decode(encoding, outputs, module_name=name, detach_grad=True, loss_mask=loss_mask)
-        self.did_fire[name][encoding.latent_indices.flatten()] = True
+        self.did_fire[name].index_fill_(0, encoding.latent_indices.flatten(), True)  # (indexed assignment syncs on HIP)
         self.last_fvu[name] = out.fvu.detach()
         loss = out.fvu / acc_steps
         loss.backward()
