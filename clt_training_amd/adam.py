@@ -27,6 +27,17 @@ class Adam(torch.optim.Optimizer):
         self._step = 0
         self._tables = {}  # key: tuple of param ids with grads -> static device tables
 
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["clt_step"] = self._step  # one step count for all parameters (torch keeps one per parameter)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        self._step = sd.pop("clt_step", self._step)
+        super().load_state_dict(sd)
+        self._tables = {}  # the cached pointer tables name the state tensors that were just replaced
+
     def _state(self, p):
         st = self.state[p]
         if not st:

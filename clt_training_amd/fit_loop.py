@@ -1,0 +1,127 @@
+"""The parts of the reference ``Trainer`` around the step that both trainers here share (sparsify/trainer.py):
+attaching a frozen HF model (:73-111), the k schedule (:263-265, 356-374, 804), and ``fit`` with its logging keys,
+checkpoint cadence and resume offset (:376-443, 818-861)."""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FitLoop:
+    # set by the trainers: cfg, dataset, model, saes, num_tokens_since_fired, global_step, step(), save()
+    wandb_log: Optional[Callable[[dict, int], None]] = None  # ``wandb.log``-shaped sink for the reference's keys
+
+    # ------------------------------------------------------------------ model attachment (trainer.py:73-111, 149)
+    @staticmethod
+    def attach_model(cfg, dataset, model):
+        """-> (dataset of step dicts, input_widths, num_batches, device) for a frozen HF ``model``."""
+        from .activations import ModelActivations, resolve_hookpoints, resolve_widths
+
+        resolve_hookpoints(cfg, model)
+        cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
+        cfg.layer_stride = 1  # applied
+        widths = resolve_widths(model, cfg.hookpoints)
+        acts = ModelActivations(model, dataset, cfg)
+        return acts, widths, len(acts), model.device
+
+    # ------------------------------------------------------------------ k schedule
+    def init_k_schedule(self):
+        num_latents = next(iter(self.saes.values())).num_latents
+        self.initial_k = min(num_latents, self.cfg.sae.k * self.cfg.k_anneal_mul)  # trainer.py:263-265
+        self.final_k = self.cfg.sae.k
+        self.best_loss = {name: float("inf") for name in self.cfg.hookpoints}
+
+    def get_current_k(self) -> int:
+        """trainer.py:356-362: linear decay from ``initial_k`` to ``final_k`` over ``k_decay_steps``."""
+        if self.global_step >= self.cfg.k_decay_steps:
+            return self.final_k
+        progress = self.global_step / self.cfg.k_decay_steps
+        return round(self.initial_k * (1 - progress) + self.final_k * progress)
+
+    def set_correct_k(self):
+        """trainer.py:364-374 (called after each optimizer step, :804)."""
+        if self.cfg.per_layer_k:
+            assert len(self.cfg.per_layer_k) == len(self.saes), "Must specify a k for each layer"
+            for i, sae in enumerate(self.saes.values()):
+                sae.cfg.k = self.cfg.per_layer_k[i]
+        else:
+            k = self.get_current_k()
+            for sae in self.saes.values():
+                sae.cfg.k = k
+
+    # ------------------------------------------------------------------ fit (trainer.py:376-443, 684, 818-861)
+    def default_path(self) -> str:
+        return f'{self.cfg.save_dir}/{self.cfg.run_name or "unnamed"}'  # trainer.py:968
+
+    def _dead_fraction(self, name: str) -> float:
+        mask = self.num_tokens_since_fired[name] > self.cfg.dead_feature_threshold
+        frac = mask.mean(dtype=torch.float32)
+        comm = getattr(self, "comm", None)
+        if comm is not None and comm.world > 1:  # equal latent shards: the mean of the shard fractions
+            frac = comm.all_reduce_(frac.clone()) / comm.world
+        return frac.item()
+
+    def fit(self, log: Optional[Callable[[int, dict], None]] = None):
+        torch.set_float32_matmul_precision("high")  # trainer.py:378
+        cfg = self.cfg
+        rank_zero = not dist.is_initialized() or dist.get_rank() == 0
+        if cfg.log_to_wandb and self.wandb_log is None:  # trainer.py:386-400
+            import importlib.util
+
+            if importlib.util.find_spec("wandb") is None:  # the same answer on every rank
+                if rank_zero:
+                    print("Weights & Biases not available, skipping logging.")
+                cfg.log_to_wandb = False
+            elif rank_zero:
+                import wandb
+
+                wandb.init(name=cfg.run_name, project="sparsify", config=cfg.to_dict(), save_code=True)
+                self.wandb_log = lambda info, step: wandb.log(info, step=step)
+        # Under tp the dead-latent fraction is a collective: every rank must take the logging branch together, so a
+        # hand-set ``wandb_log`` sink goes on every rank or on none.
+        do_log = cfg.log_to_wandb or self.wandb_log is not None
+        dataset = self.dataset
+        if self.global_step > 0 and not cfg.restart_epoch and hasattr(dataset, "skip"):
+            dataset = dataset.skip(self.global_step)  # trainer.py:410-417
+        denom = cfg.grad_acc_steps * cfg.micro_acc_steps * cfg.wandb_log_frequency
+        avg_fvu = {}
+        for batch in dataset:
+            fvus = self.step(batch)
+            for name, f in fvus.items():  # stays on the device: no host sync per hook (the reference's float(), :648)
+                avg_fvu[name] = avg_fvu.get(name, 0.0) + f.detach() / denom
+            step, substep = divmod(self.global_step, cfg.grad_acc_steps)  # step() has advanced global_step (:791, 858)
+            if substep == 0:
+                if (step + 1) % cfg.save_every == 0:  # trainer.py:818-823
+                    self.save()
+                    if cfg.save_best:
+                        self.save_best({n: float(v) for n, v in avg_fvu.items()})
+                if do_log and (step + 1) % cfg.wandb_log_frequency == 0:
+                    info = {}  # trainer.py:829-851
+                    for name in self.saes:
+                        info[f"dead_pct/{name}"] = self._dead_fraction(name)  # collective under tp: every rank calls
+                        info[f"fvu/{name}"] = float(avg_fvu[name])
+                    info["k"] = self.get_current_k()
+                    if self.wandb_log is not None:
+                        self.wandb_log(info, step)
+                avg_fvu.clear()
+            if log is not None:
+                log(self.global_step, fvus)
+        self.save()  # trainer.py:861
+        return self
+
+    def save_best(self, avg_loss: dict):
+        """trainer.py:972-993: one checkpoint per hookpoint whose running loss is the lowest so far."""
+        base = f"{self.default_path()}/best"
+        for name in self.saes:
+            if avg_loss.get(name, float("inf")) < self.best_loss[name]:
+                self.best_loss[name] = avg_loss[name]
+                self.save(f"{base}/{name}", only=[name])
+
+    def save_config(self, path):
+        Path(path).mkdir(parents=True, exist_ok=True)
+        with open(Path(path) / "config.json", "w") as f:  # trainer.py:949
+            json.dump(self.cfg.to_dict(), f)

@@ -16,18 +16,21 @@ import torch.distributed as dist
 from .adam import Adam
 from .config import TrainConfig
 from .engine import CLTEngine, Comm, ShardedCoder
+from .fit_loop import FitLoop
 from .trainer import WarmupLinearSchedule
 
 
-class TPTrainer:
+class TPTrainer(FitLoop):
     def __init__(self, cfg: TrainConfig, dataset, model=None, mesh=None, *, device="cuda",
                  input_widths: Optional[dict] = None, num_batches: Optional[int] = None, ops=None, group=None,
                  optimizer_cls=None, coders: Optional[list] = None, comm: Optional[Comm] = None):
-        assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
-        if cfg.optimizer != "adam" or cfg.loss_fn != "fvu":
+        if cfg.optimizer not in ("adam", "adam8") or cfg.loss_fn != "fvu":  # adam8 without torchao = Adam (:155-164)
             raise NotImplementedError("only optimizer='adam', loss_fn='fvu' are on the MI355X hot path")
+        if model is not None:  # frozen HF model + token rows: every rank feeds its own shard of the sequences
+            dataset, input_widths, num_batches, device = self.attach_model(cfg, dataset, model)
+        assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
         cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
-        self.cfg, self.dataset = cfg, dataset
+        self.cfg, self.dataset, self.model = cfg, dataset, model
         self.device = torch.device(device)
         self.comm = comm or Comm(group)
         if ops is None:
@@ -77,6 +80,7 @@ class TPTrainer:
         self.num_tokens_in_step = 0
         self.last_fvu = {}
         self._enc_stream = None
+        self.init_k_schedule()
 
     @torch.no_grad()
     def step(self, batch: dict):
@@ -151,6 +155,7 @@ class TPTrainer:
                 opt.zero_grad()
             for sch in self.lr_schedulers:
                 sch.step()
+            self.set_correct_k()  # trainer.py:804
             with torch.no_grad():  # trainer.py:806-816
                 for name, counts in self.num_tokens_since_fired.items():
                     counts += self.num_tokens_in_step
@@ -162,7 +167,7 @@ class TPTrainer:
         return self.last_fvu
 
     # ------------------------------------------------------------------ checkpoint (trainer.py:910-964, 258-348)
-    def save(self, path):
+    def save(self, path=None, only=None):
         """``{path}/{hookpoint}/sae.safetensors + cfg.json`` in the reference's unsharded format (the latent shards are
         gathered to rank 0), ``lr_scheduler_0.pt``, ``state.pt`` (global_step) and ``rank_{r}_state.pt``
         (num_tokens_since_fired) as the reference writes them.  The optimizer state stays sharded:
@@ -170,14 +175,16 @@ class TPTrainer:
         on a different tp degree is not supported here)."""
         from pathlib import Path
 
-        path = Path(path)
+        path = Path(path or self.default_path())
         rank = self.comm.rank
         if rank == 0:
             path.mkdir(parents=True, exist_ok=True)
+            self.save_config(path)
         if self.comm.world > 1:
             dist.barrier(group=self.comm.group)
         for name, sae in self.saes.items():
-            sae.save_to_disk(path / name, self.comm)
+            if only is None or name in only:
+                sae.save_to_disk(path / name, self.comm)
         opt = self.optimizers[0]
         torch.save({"state": opt.state_dict(), "step": getattr(opt, "_step", None)}, path / f"optimizer_0.rank{rank}.pt")
         torch.save({"num_tokens_since_fired": {h: t.cpu() for h, t in self.num_tokens_since_fired.items()}},
@@ -211,11 +218,4 @@ class TPTrainer:
         fired = torch.load(path / f"rank_{rank}_state.pt", map_location=self.device, weights_only=True)
         for h, t in fired["num_tokens_since_fired"].items():
             self.num_tokens_since_fired[h].copy_(t)
-        return self
-
-    def fit(self, log=None):
-        for batch in self.dataset:
-            fv = self.step(batch)
-            if log is not None:
-                log(self.global_step, fv)
         return self

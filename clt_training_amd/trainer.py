@@ -19,6 +19,7 @@ from torch import Tensor
 from . import fused_state
 from .adam import Adam
 from .config import TrainConfig
+from .fit_loop import FitLoop
 from .runner import CrossLayerRunner
 from .sparse_coder import SparseCoder
 
@@ -38,21 +39,27 @@ class WarmupLinearSchedule(torch.optim.lr_scheduler.LambdaLR):
                    / float(max(1, self.num_training_steps - self.warmup_steps)))
 
 
-class Trainer:
+class Trainer(FitLoop):
     """``Trainer(cfg, dataset, model=None, mesh=None)``.
 
-    ``cfg.hookpoints`` names the layers in network order; ``dataset`` is a sized iterable of
+    With ``model=None``: ``cfg.hookpoints`` names the layers in network order; ``dataset`` is a sized iterable of
     steps, each a dict ``hookpoint -> (inputs, outputs)`` of cached activations already on
     the GPU (and optionally ``"loss_mask" -> bool[N]``); ``input_widths`` maps hookpoints to
-    d_model (inferred from the first batch when omitted)."""
+    d_model (inferred from the first batch when omitted).
+    With a frozen HF ``model``: ``dataset`` yields ``{"input_ids": ...}`` rows as in the reference and the step dicts
+    come from forward hooks on the model (``activations.ModelActivations``)."""
 
     def __init__(self, cfg: TrainConfig, dataset, model=None, mesh=None, *, device="cuda",
                  input_widths: Optional[dict] = None, num_batches: Optional[int] = None):
         if mesh is not None:
             raise NotImplementedError("use clt_training_amd.tp for latent sharding over RCCL")
-        assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
-        if cfg.optimizer != "adam":
+        if cfg.optimizer == "adam8":  # trainer.py:155-164: torchao's 8-bit Adam when importable, else plain Adam
+            print("torchao 8-bit Adam not available, using Adam")
+        elif cfg.optimizer != "adam":
             raise NotImplementedError("only optimizer='adam' is on the MI355X hot path")
+        if model is not None:
+            dataset, input_widths, num_batches, device = self.attach_model(cfg, dataset, model)
+        assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
         if cfg.loss_fn != "fvu":
             raise NotImplementedError("only loss_fn='fvu' is on the MI355X hot path")
         cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
@@ -108,6 +115,7 @@ class Trainer:
         self.runner = CrossLayerRunner()
         self.last_fvu = {}
         self.num_tokens_in_step = 0
+        self.init_k_schedule()
 
     # ------------------------------------------------------------------ step-0 init (trainer.py:547-592)
     @torch.no_grad()
@@ -172,6 +180,7 @@ class Trainer:
                 optimizer.zero_grad()
             for scheduler in self.lr_schedulers:
                 scheduler.step()
+            self.set_correct_k()  # trainer.py:804 (before global_step advances, :858)
             with torch.no_grad():
                 for name, counts in self.num_tokens_since_fired.items():
                     counts += self.num_tokens_in_step
@@ -182,17 +191,45 @@ class Trainer:
         self.global_step += 1
         return self.last_fvu
 
-    def fit(self, log: Optional[Callable[[int, dict], None]] = None):
-        torch.set_float32_matmul_precision("high")  # trainer.py:378
-        for batch in self.dataset:
-            fvus = self.step(batch)
-            if log is not None:
-                log(self.global_step, fvus)
-        return self
+    # ------------------------------------------------------------------ checkpoint (trainer.py:910-970, 275-354)
+    def save(self, path=None, only=None):
+        """``{path}/{hookpoint}/sae.safetensors + cfg.json``, ``optimizer_0.pt``, ``lr_scheduler_0.pt``, ``state.pt``,
+        ``config.json`` and ``rank_0_state.pt`` as the reference lays them out."""
+        from pathlib import Path
 
-    def save(self, path):
+        path = Path(path or self.default_path())
+        path.mkdir(parents=True, exist_ok=True)
         for name, sae in self.saes.items():
-            sae.save_to_disk(f"{path}/{name}")
+            if only is None or name in only:
+                sae.save_to_disk(f"{path}/{name}")
+        torch.save(self.optimizers[0].state_dict(), path / "optimizer_0.pt")
+        torch.save(self.lr_schedulers[0].state_dict(), path / "lr_scheduler_0.pt")
+        torch.save({"global_step": self.global_step}, path / "state.pt")
+        self.save_config(path)
+        torch.save({"num_tokens_since_fired": {h: t.cpu() for h, t in self.num_tokens_since_fired.items()},
+                    "best_loss": self.best_loss}, path / "rank_0_state.pt")
+
+    def load_state(self, path):
+        """trainer.py:275-354: resume from ``save(path)``."""
+        from pathlib import Path
+
+        path = Path(path)
+        self.global_step = torch.load(path / "state.pt", weights_only=True)["global_step"]
+        rank_state = torch.load(path / "rank_0_state.pt", map_location=self.device, weights_only=True)
+        for h, t in rank_state["num_tokens_since_fired"].items():
+            if h in self.num_tokens_since_fired:
+                self.num_tokens_since_fired[h].copy_(t)
+        for h, v in rank_state.get("best_loss", {}).items():
+            if h in self.best_loss:
+                self.best_loss[h] = v
+        self.lr_schedulers[0].load_state_dict(torch.load(path / "lr_scheduler_0.pt", weights_only=True))
+        self.optimizers[0].load_state_dict(torch.load(path / "optimizer_0.pt", map_location=self.device, weights_only=True))
+        for name, sae in self.saes.items():
+            if (path / name).exists():
+                sae.load_state(f"{path}/{name}")
+            else:
+                print(f"No checkpoint found for {name} at {path}, skipping")
+        return self
 
 
 SaeTrainer = Trainer

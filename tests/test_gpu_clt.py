@@ -282,3 +282,80 @@ def test_trainer_fused_adam_equals_grad_then_adam(monkeypatch):
         for n in pa:
             assert torch.equal(pa[n], pb[n]), n
         assert fv_a == fv_b
+
+
+@pytest.mark.parametrize("which", ["autograd", "engine"])
+def test_model_driven_fit_and_resume(which, tmp_path):
+    """SURVEY.md section 8f rank 2 (trainer.py:73-111, 472-545, 684-692, 818-861, 275-354): a frozen random-init GPT-2
+    drives ``fit`` through forward hooks; the parameters equal those of the same trainer fed the cached activations, and
+    a run saved after two steps and resumed in a fresh trainer (``load_state`` + the dataset offset of :410-417) ends
+    with the same parameters as the uninterrupted run."""
+    transformers = pytest.importorskip("transformers")
+    from clt_training_amd import SparseCoderConfig, TrainConfig, Trainer
+    from clt_training_amd.activations import ModelActivations
+    from clt_training_amd.tp import TPTrainer
+
+    cls = Trainer if which == "autograd" else TPTrainer
+    torch.manual_seed(0)
+    mcfg = transformers.GPT2Config(n_layer=3, n_embd=32, n_head=2, vocab_size=50, n_positions=32, bos_token_id=1,
+                                   eos_token_id=1, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
+    model = transformers.GPT2LMHeadModel(mcfg).eval().to(DEV)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(2, 50, (16, 32), generator=g)
+    ids[:, 0] = 1
+
+    class Rows(list):  # a list of rows with the `select` the resume path asks of a dataset (trainer.py:411-417)
+        def select(self, rng):
+            return Rows(self[i] for i in rng)
+
+    rows = Rows({"input_ids": r} for r in ids)
+
+    def make(run, hooks):
+        torch.manual_seed(0)
+        cfg = TrainConfig(sae=SparseCoderConfig(transcode=True, expansion_factor=8, k=8, skip_connection=True),
+                          hookpoints=hooks, cross_layer=3, optimizer="adam", lr=1e-2, lr_warmup_steps=2, batch_size=4,
+                          remove_first_token=True, log_to_wandb=False, save_dir=str(tmp_path), run_name=run, save_every=2)
+        return cfg
+
+    def params(tr):
+        return {f"{h}.{n}": p.detach().clone() for h, s in tr.saes.items() for n, p in s.named_parameters()}
+
+    def warm(tr):  # transcoder decoders start at zero
+        gg = torch.Generator(device=DEV).manual_seed(1)
+        with torch.no_grad():
+            for s in tr.saes.values():
+                for n, p in s.named_parameters():
+                    if n.startswith("W_dec"):
+                        p.copy_((0.1 * torch.randn(p.shape, generator=gg, device=DEV)).to(p.dtype))
+
+    # ---- model-driven, 4 steps; checkpoints land after steps 1 and 3 (save_every=2: (step + 1) % 2 == 0 with step = 1, 3)
+    tr = cls(make("driven", ["h.*.mlp"]), rows, model)
+    warm(tr)
+    tr.fit()
+    assert tr.global_step == 4 and tr.cfg.hookpoints == ["h.0.mlp", "h.1.mlp", "h.2.mlp"]
+    want = params(tr)
+
+    # ---- cached activations, the same 4 steps
+    cfg2 = make("cached", ["h.0.mlp", "h.1.mlp", "h.2.mlp"])
+    cached = list(ModelActivations(model, rows, cfg2))
+    tr2 = cls(cfg2, cached, device=DEV, num_batches=4)
+    warm(tr2)
+    for b in cached:
+        tr2.step(b)
+    got = params(tr2)
+    for n in want:
+        assert torch.equal(want[n], got[n]), n
+
+    # ---- resume: one step, save, fresh trainer, load_state, fit the rest
+    tr3 = cls(make("resume", ["h.*.mlp"]), rows, model)
+    warm(tr3)
+    tr3.step(next(iter(tr3.dataset)))
+    tr3.save()
+    tr4 = cls(make("resume", ["h.*.mlp"]), rows, model)
+    tr4.load_state(f"{tmp_path}/resume")
+    assert tr4.global_step == 1
+    tr4.fit()
+    assert tr4.global_step == 4
+    got = params(tr4)
+    for n in want:
+        torch.testing.assert_close(got[n], want[n], rtol=0, atol=0, msg=n)
