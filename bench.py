@@ -88,7 +88,7 @@ def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.
         return es * (6 * M * d + N * k / world * d), "byte"
     if name == "clt_decode_bwd_rows":
         return es * (2 * M * d + N * k / world * d), "byte"
-    if name in ("clt_encoder_gemm_relu", "clt_encode_topk_fwd"):  # the fused call is priced as its GEMM alone
+    if name in ("clt_encoder_gemm_relu", "clt_encode_topk_fwd", "clt_encode_groupmax_fwd"):  # the fused call is priced as its GEMM alone
         return 2.0 * N * d * M, "flop"
     if name == "clt_topk_rows":
         return N * M * es, "byte"
@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--sae", action="store_true",
                     help="plain SAE per hookpoint (no transcoding, no skip, unit-norm decoder): BASELINE configs[3] shape "
                          "with --layers 1 --d-model 4096 --expansion 32 --k 192; a secondary data point, not the metric")
+    ap.add_argument("--activation", default="topk", choices=["topk", "groupmax"],
+                    help="groupmax (fused_encoder.py:373-413) is a secondary data point, not the metric")
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="rehearse rank 0's compute of a W-rank run on one GPU (collectives are local stand-ins; "
                          "NOT a measurement of the metric: the line is marked 'simulated')")
@@ -151,7 +153,7 @@ def main():
     N = args.tokens
     hooks = [f"h.{i}.mlp" for i in range(L)]
     sae_cfg = SparseCoderConfig(dtype=args.dtype if args.dtype == "bfloat16" else "none", expansion_factor=args.expansion,
-                                k=k, transcode=not args.sae, skip_connection=not args.sae)
+                                k=k, transcode=not args.sae, skip_connection=not args.sae, activation=args.activation)
     cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=0 if args.sae else L, optimizer="adam", lr=2e-4,
                       lr_warmup_steps=50, log_to_wandb=False)
     act_dtype = torch.bfloat16 if args.dtype == "bfloat16" else torch.float32
@@ -266,7 +268,7 @@ def main():
             "host_issue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": f"GPT-2 small CLT: {L} layers, cross_layer={L}, d={d}, latents={M}, k={k}, "
-                                   f"skip_connection, {args.dtype} weights, Adam; {N} tokens/step/GPU "
+                                   f"skip_connection, {args.dtype} weights, Adam{'' if args.activation == 'topk' else ', ' + args.activation}; {N} tokens/step/GPU "
                                    f"(BASELINE.json configs[1])",
                        "tokens_per_step": tokens_per_step, "params_per_gpu": P_total, "parallelism": parallelism},
             "fvu_last": round(float(sum(float(v) for v in fv.values()) / len(fv)), 5),

@@ -172,3 +172,112 @@ extern "C" int clt_topk_rows(const void* vals, int val_dtype, int64_t ld, const 
   return topk_rows_gated(vals, val_dtype, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, nullptr,
                          (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// groupmax (fused_encoder.py:373-413): the M latents of a row are k consecutive groups of M / k; each group keeps its
+// largest pre-activation (ties: lowest index, torch's CPU rule) -- out[n, g] = max, idx[n, g] = g * (M / k) + argmax.
+// One wave per (row, group): the group is a contiguous run of the row, read once in 16-byte chunks (HBM-bound:
+// N * M * sizeof(T) bytes per call).  Within a lane the indices ascend, so a strict '>' keeps the lowest; across lanes
+// the reduction compares (value, then index).
+namespace clt {
+
+template <typename VT, typename OT, bool VEC>
+__global__ __launch_bounds__(256) void groupmax_rows_kernel(const VT* __restrict__ vals, int64_t ld, int64_t N, int k,
+                                                            int gs, OT* __restrict__ out_vals,
+                                                            int64_t* __restrict__ out_idx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // (row, group), group fastest
+  if (unit >= N * k) return;  // wave-uniform
+  const int64_t row = unit / k;
+  const int g = (int)(unit - row * k);
+  const VT* p = vals + row * ld + (int64_t)g * gs;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (VEC) {
+    constexpr int E = Chunk<VT>::E;
+    for (int c = lane; c * E < gs; c += 64) {
+      float f[E];
+      Chunk<VT>::load(p + c * E, f);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (f[e] > best) {
+          best = f[e];
+          bi = c * E + e;
+        }
+    }
+  } else {
+    for (int i = lane; i < gs; i += 64) {
+      const float f = (float)p[i];
+      if (f > best) {
+        best = f;
+        bi = i;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (lane == 0) {
+    out_vals[unit] = (OT)best;
+    out_idx[unit] = (int64_t)g * gs + bi;
+  }
+}
+
+}  // namespace clt
+
+extern "C" int clt_groupmax_rows(const void* vals, int val_dtype, int64_t ld, int64_t N, int64_t M, int k,
+                                 void* out_vals, int out_dtype, int64_t* out_idx, clt_stream_t stream) {
+  using namespace clt;
+  CLT_CHECK_ARG(vals && out_vals && out_idx, "clt_groupmax_rows: null pointer");
+  CLT_CHECK_ARG(valid_dtype(val_dtype) && valid_dtype(out_dtype), "clt_groupmax_rows: bad dtype");
+  CLT_CHECK_ARG(N >= 0 && M > 0 && M < (1ll << 31) && k >= 1 && k <= M && ld >= M, "clt_groupmax_rows: bad sizes");
+  CLT_CHECK_ARG(M % k == 0, "clt_groupmax_rows: k=%d must divide the %lld latents (fused_encoder.py:409)", k, (long long)M);
+  if (N == 0) return CLT_OK;
+  const int gs = (int)(M / k);
+  const size_t es = dtype_size(val_dtype);
+  const bool vec = aligned16(vals) && (ld * es) % 16 == 0 && (gs * es) % 16 == 0;
+  const int64_t units = N * k;
+  CLT_CHECK_ARG((units + 3) / 4 < (1ll << 31), "clt_groupmax_rows: too many (row, group) pairs");
+  dim3 grid((unsigned)((units + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define CLT_GM(VT, OT)                                                                                              \
+  do {                                                                                                              \
+    if (vec)                                                                                                        \
+      hipLaunchKernelGGL((groupmax_rows_kernel<VT, OT, true>), grid, block, 0, st, (const VT*)vals, ld, N, k, gs,   \
+                         (OT*)out_vals, out_idx);                                                                   \
+    else                                                                                                            \
+      hipLaunchKernelGGL((groupmax_rows_kernel<VT, OT, false>), grid, block, 0, st, (const VT*)vals, ld, N, k, gs,  \
+                         (OT*)out_vals, out_idx);                                                                   \
+  } while (0)
+  if (val_dtype == CLT_BF16 && out_dtype == CLT_BF16) CLT_GM(bf16_t, bf16_t);
+  else if (val_dtype == CLT_BF16) CLT_GM(bf16_t, float);
+  else if (out_dtype == CLT_BF16) CLT_GM(float, bf16_t);
+  else CLT_GM(float, float);
+#undef CLT_GM
+  CLT_CHECK_LAUNCH("clt_groupmax_rows");
+  return CLT_OK;
+}
+
+// relu(x W^T + b) -> groupmax: the GEMM writes the pre-activation matrix into the workspace (same size rule as
+// clt_encode_topk_workspace_bytes), the row pass above reads it once.
+extern "C" int clt_encode_groupmax_fwd(const void* x, const void* W, int in_dtype, const void* bias, int bias_dtype,
+                                       int64_t N, int64_t M, int d, int k, void* out_vals, int out_dtype,
+                                       int64_t* out_idx, void* workspace, size_t workspace_bytes, clt_stream_t stream) {
+  using namespace clt;
+  CLT_CHECK_ARG(workspace && aligned16(workspace), "clt_encode_groupmax_fwd: workspace must be a 16-byte aligned pointer");
+  CLT_CHECK_ARG(M > 0 && k >= 1 && M % k == 0, "clt_encode_groupmax_fwd: k must divide the latent count");
+  const size_t need = clt_encode_topk_workspace_bytes(N, M, out_dtype);
+  if (workspace_bytes < need) {
+    set_error("clt_encode_groupmax_fwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return CLT_ERR_WORKSPACE;
+  }
+  int rc = clt_encoder_gemm_relu(x, W, in_dtype, bias, bias_dtype, workspace, out_dtype, N, M, d, stream);
+  if (rc != CLT_OK) return rc;
+  return clt_groupmax_rows(workspace, out_dtype, M, N, M, k, out_vals, out_dtype, out_idx, stream);
+}

@@ -368,9 +368,21 @@ class CLTEngine:
         xn_r = x_r.float() * (d**0.5 / lp.in_norm) if cfg.normalize_io else x_r
         x_enc_r = xn_r if cfg.transcode else xn_r.float() - lp.b_decs[0]
         x_enc = comm.all_gather_rows(x_enc_r.to(cd))
-        v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, k, out_dtype=cd)
-        if comm.world > 1:
-            v, idx = self._merge_candidates(v, idx + lp.lat_begin, k)
+        if cfg.activation == "groupmax":
+            # fused_encoder.py:373-413: the k groups are runs of consecutive latents, so each shard owns k / tp whole
+            # groups and the exchange is a plain concatenation (one all-gather of value bits | global index)
+            assert k % comm.world == 0, "groupmax: k must be a multiple of the tp degree (fused_encoder.py:377)"
+            v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, k // comm.world, out_dtype=cd, activation="groupmax")
+            if comm.world > 1:
+                packed = (v.float().view(torch.int32).to(torch.int64) << 32) | (idx + lp.lat_begin)
+                win = comm.all_gather_cat1(packed)
+                v, idx = (win >> 32).to(torch.int32).view(torch.float32).to(cd), win & 0xFFFFFFFF
+        else:
+            if cfg.activation != "topk":
+                raise NotImplementedError(f"activation {cfg.activation!r}")
+            v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, k, out_dtype=cd)
+            if comm.world > 1:
+                v, idx = self._merge_candidates(v, idx + lp.lat_begin, k)
         return dict(xn_r=self._keep_input(j, xn_r.to(cd)), x_enc=x_enc, v=v, idx=idx)
 
     @torch.no_grad()

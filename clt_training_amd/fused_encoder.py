@@ -67,16 +67,17 @@ class FusedEncoder(torch.autograd.Function):
 
 def fused_encoder(input: Tensor, weight: Tensor, bias: Tensor, k: int,
                   activation: Literal["groupmax", "topk"] = "topk", use_fp8: bool = False) -> EncoderOutput:
-    """input (N, D), weight (M, D), bias (M,) -> top-k values / indices (fused_encoder.py:293-309)."""
-    if activation != "topk":
-        raise NotImplementedError(f"activation {activation!r}: only 'topk' is on the MI355X hot path")
+    """input (N, D), weight (M, D), bias (M,) -> top-k (or, :373-413, groupmax) values / indices
+    (fused_encoder.py:293-309)."""
+    if activation not in ("topk", "groupmax"):
+        raise NotImplementedError(f"activation {activation!r}: 'topk' and 'groupmax' are on the MI355X hot path")
     if use_fp8:
         raise NotImplementedError("use_fp8 is out of scope (no BASELINE config uses it)")
     with torch.no_grad():
         cd = _compute_dtype(input, weight)
         x = input if input.dtype == cd else input.to(cd)
         W = weight if weight.dtype == cd else weight.to(cd)
-        values, indices = ops.encode_topk(x, W, bias, k, out_dtype=cd)
+        values, indices = ops.encode_topk(x, W, bias, k, out_dtype=cd, activation=activation)
     indices._clt_seg = SegmentsHolder()
     values = FusedEncoder.apply(input, weight, bias, values, indices, activation)
     return EncoderOutput(top_acts=values, top_indices=indices)

@@ -124,8 +124,22 @@ def topk_rows(vals: Tensor, k: int, cand_idx: Optional[Tensor] = None, counts: O
     return ov, oi
 
 
-def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=None):
-    """relu(x W^T + b) -> row top-k (fused_encoder.py:310-322,372)."""
+def groupmax_rows(vals: Tensor, k: int, out_dtype=None):
+    """Largest entry of each of the k consecutive column groups of every row (fused_encoder.py:408-413)."""
+    assert vals.dim() == 2 and vals.stride(1) == 1
+    N, M = vals.shape
+    ld = vals.stride(0) if N > 1 else M
+    out_dtype = out_dtype or vals.dtype
+    ov = torch.empty(N, k, dtype=out_dtype, device=vals.device)
+    oi = torch.empty(N, k, dtype=torch.int64, device=vals.device)
+    _call("clt_groupmax_rows", _ptr(vals), _dt(vals), ld, N, M, k, _ptr(ov), _DT[out_dtype], _ptr(oi), _stream(vals))
+    return ov, oi
+
+
+def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=None, activation: str = "topk"):
+    """relu(x W^T + b) -> row top-k (fused_encoder.py:310-322,372) or groupmax (:373-413)."""
+    if activation not in ("topk", "groupmax"):
+        raise NotImplementedError(f"activation {activation!r}: 'topk' and 'groupmax' are on the MI355X hot path")
     x, W = _c(x), _c(W)
     assert x.dtype == W.dtype and x.shape[1] == W.shape[1]
     N, d = x.shape
@@ -138,7 +152,8 @@ def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=Non
     ov = torch.empty(N, k, dtype=out_dtype, device=x.device)
     oi = torch.empty(N, k, dtype=torch.int64, device=x.device)
     # one entry point: the fused sample / filter / merge launches for bf16, GEMM + row top-k otherwise
-    _call("clt_encode_topk_fwd", _ptr(x), _ptr(W), _dt(x), _ptr(b), _dt(b) if b is not None else 0, N, M, d, k,
+    _call("clt_encode_topk_fwd" if activation == "topk" else "clt_encode_groupmax_fwd",
+          _ptr(x), _ptr(W), _dt(x), _ptr(b), _dt(b) if b is not None else 0, N, M, d, k,
           _ptr(ov), _DT[out_dtype], _ptr(oi), _ptr(ws), ws.numel(), _stream(x))
     return ov, oi
 

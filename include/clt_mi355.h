@@ -76,6 +76,21 @@ int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, const void* 
                         int64_t N, int64_t M, int d, int k, void* out_vals, int out_dtype, int64_t* out_idx,
                         void* workspace, size_t workspace_bytes, clt_stream_t stream);
 
+/* groupmax activation: replaces `preacts.unflatten(-1, (k, -1)).max(dim=-1)` + the group offsets
+ * (fused_encoder.py:408-413).  vals [N,M] (leading dimension ld), k must divide M; out_vals [N,k] = the largest
+ * entry of each run of M/k consecutive columns, out_idx [N,k] int64 = its column (ties: the lowest column, torch's
+ * CPU rule; an all-zero post-ReLU group reports its first column with value 0).  Output order: group order.
+ * Under latent sharding each rank calls it on its [N, M/tp] block with k/tp groups and adds its column offset
+ * (fused_encoder.py:374-389).  */
+int clt_groupmax_rows(const void* vals, int val_dtype, int64_t ld, int64_t N, int64_t M, int k, void* out_vals,
+                      int out_dtype, int64_t* out_idx, clt_stream_t stream);
+
+/* Fused convenience for activation="groupmax" (fused_encoder.py:310-312, 373-413): encoder GEMM + bias + ReLU into
+ * the workspace (clt_encode_topk_workspace_bytes), then clt_groupmax_rows.  */
+int clt_encode_groupmax_fwd(const void* x, const void* W, int in_dtype, const void* bias, int bias_dtype,
+                            int64_t N, int64_t M, int d, int k, void* out_vals, int out_dtype, int64_t* out_idx,
+                            void* workspace, size_t workspace_bytes, clt_stream_t stream);
+
 /* ------------------------------------------------------------------ decoder
  * Replaces decoder_impl / xformers_embedding_bag forward (utils.py:442-457,
  * xformers.py:15-90) with the post-encoder affine (sparse_coder.py:136-140) and the

@@ -65,10 +65,23 @@ def topk_lowest_index(pre: Tensor, k: int):
     return vals[:, :k].contiguous(), idx[:, :k].contiguous()
 
 
-def encoder_forward(x, W, b, k, out_dtype=None):
-    """fused_encoder(..., activation="topk") forward -- fused_encoder.py:310-322,372."""
+def groupmax(pre: Tensor, k: int):
+    """fused_encoder.py:408-413: k consecutive groups of M / k columns; value and column of each group's maximum
+    (ties: the lowest column -- what ``Tensor.max(dim)`` returns on CPU)."""
+    n, m = pre.shape
+    assert m % k == 0
+    gs = m // k
+    grp = pre.reshape(n, k, gs)
+    vals = grp.max(dim=-1).values
+    cols = torch.arange(gs).expand_as(grp)
+    first = torch.where(grp == vals.unsqueeze(-1), cols, torch.full_like(cols, gs)).min(dim=-1).values
+    return vals.contiguous(), (first + torch.arange(0, m, gs)).contiguous()
+
+
+def encoder_forward(x, W, b, k, out_dtype=None, activation="topk"):
+    """fused_encoder(..., activation) forward -- fused_encoder.py:310-322,372 ("topk"), :373-413 ("groupmax")."""
     pre = encoder_preacts(x, W, b, out_dtype)
-    return topk_lowest_index(pre, k)
+    return topk_lowest_index(pre, k) if activation == "topk" else groupmax(pre, k)
 
 
 def topk_selection_slack(pre: Tensor, idx: Tensor) -> Tensor:
@@ -352,6 +365,7 @@ def clt_train_step(
     acc_steps: int = 1,
     act_dtype=None,
     forced_idx: Optional[list] = None,
+    activation: str = "topk",
 ) -> StepResult:
     """Explicit forward+backward of one FVU train step over all layers, in the
     order the reference's hook runs them (trainer.py:598-682): for each layer j
@@ -389,7 +403,7 @@ def clt_train_step(
         xn = _normalize_in(lp, xs[j].to(dt), normalize_io)
         x_enc = xn if lp.transcode else xn - lp.b_decs[0].to(dt)  # sparse_coder.py:637-638
         if forced_idx is None:
-            v, idx = encoder_forward(x_enc, lp.W_enc.to(dt), lp.b_enc.to(dt), k, None)
+            v, idx = encoder_forward(x_enc, lp.W_enc.to(dt), lp.b_enc.to(dt), k, None, activation)
         else:
             # reduced-precision parity: evaluate the step on a GIVEN selection (the near-tie order of a
             # bf16 GEMM is not reproducible across accumulation orders); validity of the selection is

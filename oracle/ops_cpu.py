@@ -15,11 +15,16 @@ class Segments:
         self.perm, self.offsets, self.M, self.k = perm, offsets, M, k
 
 
-def encode_topk(x, W, b, k, out_dtype=None):
+def encode_topk(x, W, b, k, out_dtype=None, activation="topk"):
     out_dtype = out_dtype or x.dtype
     pre = O.encoder_preacts(x.float(), W.float(), None if b is None else b.float(), out_dtype)
-    v, i = O.topk_lowest_index(pre, k)
+    v, i = O.topk_lowest_index(pre, k) if activation == "topk" else O.groupmax(pre, k)
     return v.to(out_dtype), i
+
+
+def groupmax_rows(vals, k, out_dtype=None):
+    v, i = O.groupmax(vals.float(), k)
+    return v.to(out_dtype or vals.dtype), i
 
 
 def topk_rows(vals, k, cand_idx=None, counts=None, out_dtype=None):

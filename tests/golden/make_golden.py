@@ -107,19 +107,22 @@ def canon(vals, idx):
 
 
 # ---------------------------------------------------------------- encoder
-def golden_encoder(name, N, d, M, k, seed):
+def golden_encoder(name, N, d, M, k, seed, activation="topk"):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, d, generator=g).requires_grad_()
     W = (torch.randn(M, d, generator=g) / d**0.5).requires_grad_()
     b = (0.1 * torch.randn(M, generator=g)).requires_grad_()
     up = torch.randn(N, k, generator=g)
-    out = fused_encoder(x, W, b, k, "topk")
+    out = fused_encoder(x, W, b, k, activation)
     vals, idx = out.top_acts, out.top_indices
     # loss 1: sum of values (tests/test_encode.py:46)
     vals.sum().backward(retain_graph=True)
     g1 = dict(gx=x.grad.clone(), gW=W.grad.clone(), gb=b.grad.clone())
     x.grad = W.grad = b.grad = None
-    cv, ci, perm = canon(vals.detach(), idx)
+    if activation == "groupmax":  # the output order IS the group order: keep it
+        cv, ci, perm = vals.detach(), idx, torch.arange(k).expand(N, k)
+    else:
+        cv, ci, perm = canon(vals.detach(), idx)
     # loss 2: random upstream grad, expressed in canonical order
     (vals * torch.zeros_like(vals).scatter_(1, perm, up)).sum().backward()
     g2 = dict(gx=x.grad.clone(), gW=W.grad.clone(), gb=b.grad.clone())
@@ -128,7 +131,7 @@ def golden_encoder(name, N, d, M, k, seed):
         dict(x=x, W=W, b=b, up=up, vals=cv, idx=ci,
              gx_sum=g1["gx"], gW_sum=g1["gW"], gb_sum=g1["gb"],
              gx_up=g2["gx"], gW_up=g2["gW"], gb_up=g2["gb"]),
-        dict(N=N, d=d, M=M, k=k, seed=seed, ref="fused_encoder.py:293-422"),
+        dict(N=N, d=d, M=M, k=k, seed=seed, activation=activation, ref="fused_encoder.py:293-422"),
     )
 
 
@@ -264,7 +267,13 @@ def golden_clt(name, cfg_kw, L, cross, N, d, seed):
                        ref="runner.py:25-201; trainer.py:117-146,598-682"))
 
 
-def main():
+def main(only=None):
+    if only == "groupmax":  # added later: leaves the earlier fixtures untouched
+        golden_encoder("encoder_groupmax", N=24, d=48, M=512, k=8, seed=12, activation="groupmax")
+        golden_single("single_transcoder_groupmax",
+                      dict(expansion_factor=8, k=8, transcode=True, skip_connection=True, activation="groupmax"),
+                      N=40, d=32, seed=13, masked=True)
+        return
     golden_encoder("encoder_a", N=32, d=48, M=512, k=8, seed=1)
     golden_encoder("encoder_b", N=16, d=64, M=256, k=32, seed=2)
     golden_decoder("decoder_d48", N=2, d=48, M=128, k=10, seed=3)  # tests/test_decode.py shapes
@@ -287,4 +296,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

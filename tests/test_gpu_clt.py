@@ -80,7 +80,8 @@ def check_against_golden(t, saes, outs, encs, single):
         assert seen >= 4
 
 
-@pytest.mark.parametrize("name", ["single_transcoder_skip", "single_transcoder_scale_norm", "single_sae"])
+@pytest.mark.parametrize("name", ["single_transcoder_skip", "single_transcoder_scale_norm", "single_sae",
+                                  "single_transcoder_groupmax"])
 def test_single_layer_vs_reference_golden(name, fp32_exact):
     t, meta = load_golden(name)
     sae = build_sae(t, meta, 0, True)

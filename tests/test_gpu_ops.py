@@ -595,3 +595,67 @@ def test_adam(dtype):
         for i, p in enumerate(ps):
             tol = FP32 if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
             torch.testing.assert_close(p.detach().float().cpu(), ref[i][0].float(), **tol)
+
+
+# ----------------------------------------------------------------------------- groupmax (fused_encoder.py:373-413)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,M,k,pad", [(37, 4096, 32, 0), (5, 120, 8, 0), (3, 12, 3, 0), (1, 64, 64, 0), (9, 1024, 1, 0),
+                                       (64, 98304, 32, 0), (17, 2048, 16, 64)])
+def test_groupmax_rows_vs_oracle(ops, dtype, N, M, k, pad):
+    """Bit-exact values and indices against the oracle (itself pinned on the reference's goldens): vector and scalar
+    group widths, a strided matrix, exact ties (the lowest column wins) and all-zero groups (first column, value 0)."""
+    g = torch.Generator().manual_seed(N * 7 + M + k)
+    pre = torch.relu(torch.randn(N, M + pad, generator=g)).to(dtype)
+    gs = M // k
+    pre[0, : gs] = 0                                  # an all-zero group
+    if gs >= 4:
+        pre[-1, gs - 1] = pre[-1, gs - 3] = 100.0     # a tie inside the first group of the last row
+        pre[-1, M - 1] = pre[-1, M - gs] = 50.0       # first and last column of the last group
+    dev = pre.to(DEV)[:, :M]
+    v, i = ops.groupmax_rows(dev, k)
+    rv, ri = O.groupmax(pre[:, :M].float(), k)
+    assert i.dtype == torch.int64 and torch.equal(i.cpu(), ri)
+    assert torch.equal(v.float().cpu(), rv)
+    assert int(i[0, 0]) == 0 and float(v[0, 0]) == 0.0
+    if gs >= 4 and k > 1:
+        assert int(i[-1, 0]) == gs - 3 and int(i[-1, -1]) == M - gs
+
+
+def test_encode_groupmax_vs_reference_golden(ops):
+    """clt_encode_groupmax_fwd and the autograd seam ``fused_encoder(..., "groupmax")`` against the golden produced by
+    the reference's own fused_encoder (fp32, rtol 1e-5; indices bit-exact)."""
+    from clt_training_amd.fused_encoder import fused_encoder
+
+    t, meta = load_golden("encoder_groupmax")
+    k = meta["k"]
+    v, i = ops.encode_topk(t["x"].to(DEV), t["W"].to(DEV), t["b"].to(DEV), k, activation="groupmax")
+    assert torch.equal(i.cpu(), t["idx"])
+    torch.testing.assert_close(v.cpu(), t["vals"], **FP32)
+    for tag in ("sum", "up"):
+        x, W, b = (t[n].to(DEV).requires_grad_() for n in ("x", "W", "b"))
+        out = fused_encoder(x, W, b, k, "groupmax")
+        assert torch.equal(out.top_indices.cpu(), t["idx"])
+        up = torch.ones_like(out.top_acts) if tag == "sum" else t["up"].to(DEV)
+        (out.top_acts * up).sum().backward()
+        torch.testing.assert_close(W.grad.cpu(), t[f"gW_{tag}"], **FP32)
+        torch.testing.assert_close(b.grad.cpu(), t[f"gb_{tag}"], **FP32)
+        torch.testing.assert_close(x.grad.cpu(), t[f"gx_{tag}"], **FP32)
+
+
+def test_encode_groupmax_bf16_layer_shape(ops):
+    """BASELINE configs[1] layer shape in bf16: the group maxima of the kernel's own bf16 pre-activations, bit for bit
+    (the GEMM is the one the top-k path's plain form uses; its parity is tested above)."""
+    g = torch.Generator().manual_seed(5)
+    N, M, d, k = 2048, 98304, 768, 32
+    x = (torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(M, d, generator=g) / math.sqrt(d)).to(torch.bfloat16).to(DEV)
+    b = (0.1 * torch.randn(M, generator=g)).to(DEV)
+    v, i = ops.encode_topk(x, W, b, k, activation="groupmax")
+    pre = ops.encoder_gemm_relu(x, W, b)
+    rv, ri = pre.view(N, k, M // k).max(dim=-1)
+    assert torch.equal(v, rv)
+    gathered = pre.gather(1, i)
+    assert torch.equal(gathered, rv)                       # the reported column holds the maximum
+    assert bool((i // (M // k) == torch.arange(k, device=DEV)).all())   # one column per group, in group order
+    first = torch.where(pre.view(N, k, -1) == rv.unsqueeze(-1), torch.arange(M // k, device=DEV), M).min(-1).values
+    assert torch.equal(i, first + torch.arange(0, M, M // k, device=DEV))  # and it is the FIRST maximum

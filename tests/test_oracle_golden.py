@@ -13,11 +13,11 @@ def scatter_up(t):
     return t["up"]
 
 
-@pytest.mark.parametrize("name", ["encoder_a", "encoder_b"])
+@pytest.mark.parametrize("name", ["encoder_a", "encoder_b", "encoder_groupmax"])
 def test_encoder_golden(name):
     t, meta = load_golden(name)
     k = meta["k"]
-    vals, idx = O.encoder_forward(t["x"], t["W"], t["b"], k)
+    vals, idx = O.encoder_forward(t["x"], t["W"], t["b"], k, activation=meta.get("activation", "topk"))
     assert torch.equal(idx, t["idx"])  # bit-exact index sets, canonical order
     torch.testing.assert_close(vals, t["vals"], **FP32)
     for tag, g in (("sum", torch.ones_like(vals)), ("up", t["up"])):
@@ -53,11 +53,15 @@ def _check_step(t, meta, layers, xs, ys, mask, single):
         coalesce=cfg.get("coalesce_topk", "none"),
         normalize_io=cfg.get("normalize_io", False),
         divide_cross_layer=cfg.get("divide_cross_layer", False),
+        activation=cfg.get("activation", "topk"),
     )
     for l in range(len(layers)):
         sfx = "" if single else f".{l}"
-        assert torch.equal(res.top_idx[l], t[f"idx{sfx}"])
-        torch.testing.assert_close(res.top_acts[l].float(), t[f"vals{sfx}"], **FP32)
+        got_v, got_i = res.top_acts[l].float(), res.top_idx[l]
+        if cfg.get("activation") == "groupmax":  # group order -> the goldens' canonical (value desc, index asc) order
+            got_v, got_i = O.topk_merge(got_v, got_i, got_v.shape[1])
+        assert torch.equal(got_i, t[f"idx{sfx}"])
+        torch.testing.assert_close(got_v, t[f"vals{sfx}"], **FP32)
         torch.testing.assert_close(res.sae_outs[l], t[f"sae_out{sfx}"], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(res.fvus[l], t[f"fvu{sfx}"], **FP32)
         gpre = "g." if single else f"g.{l}."
@@ -73,7 +77,8 @@ def _check_step(t, meta, layers, xs, ys, mask, single):
     return res
 
 
-@pytest.mark.parametrize("name", ["single_transcoder_skip", "single_transcoder_scale_norm", "single_sae"])
+@pytest.mark.parametrize("name", ["single_transcoder_skip", "single_transcoder_scale_norm", "single_sae",
+                                  "single_transcoder_groupmax"])
 def test_single_layer_golden(name):
     t, meta = load_golden(name)
     layers = golden_layers(t, meta)
@@ -93,6 +98,15 @@ def test_clt_golden(name):
     xs = [t[f"x.{l}"] for l in range(L)]
     ys = [t[f"y.{l}"] for l in range(L)]
     _check_step(t, meta, layers, xs, ys, t["mask"], single=False)
+
+
+def test_groupmax_tie_rule():
+    """fused_encoder.py:408-413: per group the first maximum; an all-zero (post-ReLU) group reports its first column."""
+    pre = torch.tensor([[0.0, 2.0, 2.0, 1.0, 0.0, 0.0, 0.0, 0.0, 5.0, 1.0, 5.0, 5.0]])
+    v, i = O.groupmax(pre, 3)
+    assert v.tolist() == [[2.0, 0.0, 5.0]] and i.tolist() == [[1, 4, 8]]
+    rv, ri = pre.unflatten(-1, (3, -1)).max(dim=-1)  # the reference's expression, on CPU
+    assert torch.equal(v, rv) and torch.equal(i, ri + torch.arange(0, 12, 4))
 
 
 def test_topk_tie_rule():

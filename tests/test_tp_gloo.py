@@ -132,6 +132,8 @@ CASES = {
     "clt_skip_scale_norm_div": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True, post_encoder_scale=True,
                                      normalize_io=True, divide_cross_layer=True), 3, 2),
     "sae": (dict(transcode=False, expansion_factor=4, k=4, normalize_decoder=False), 1, 0),
+    # fused_encoder.py:373-413: each shard owns k / tp whole groups; the exchange is a concatenation
+    "clt_groupmax": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True, activation="groupmax"), 3, 3),
 }
 
 
@@ -152,7 +154,8 @@ def run_case(case, tmp_path, device="cpu", resume=False):
         if not sae_kw["transcode"]:
             xs = ys  # an SAE reconstructs its own input (trainer.py:524)
         r = O.clt_train_step(layers, xs, ys, m, sae_kw["k"], normalize_io=sae_kw.get("normalize_io", False),
-                             divide_cross_layer=sae_kw.get("divide_cross_layer", False))
+                             divide_cross_layer=sae_kw.get("divide_cross_layer", False),
+                             activation=sae_kw.get("activation", "topk"))
         want_fvu.append([float(f) for f in r.fvus])
         lr = 1e-2 * O.warmup_linear_factor(s, 2, 4)
         for l, lp in enumerate(layers):
