@@ -125,6 +125,8 @@ def main():
                          "with --layers 1 --d-model 4096 --expansion 32 --k 192; a secondary data point, not the metric")
     ap.add_argument("--activation", default="topk", choices=["topk", "groupmax"],
                     help="groupmax (fused_encoder.py:373-413) is a secondary data point, not the metric")
+    ap.add_argument("--optimizer", default="adam", choices=["adam", "signum"],
+                    help="signum = SignSGD + linear warm-up (force_lr_warmup); a secondary data point, not the metric")
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="rehearse rank 0's compute of a W-rank run on one GPU (collectives are local stand-ins; "
                          "NOT a measurement of the metric: the line is marked 'simulated')")
@@ -154,8 +156,8 @@ def main():
     hooks = [f"h.{i}.mlp" for i in range(L)]
     sae_cfg = SparseCoderConfig(dtype=args.dtype if args.dtype == "bfloat16" else "none", expansion_factor=args.expansion,
                                 k=k, transcode=not args.sae, skip_connection=not args.sae, activation=args.activation)
-    cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=0 if args.sae else L, optimizer="adam", lr=2e-4,
-                      lr_warmup_steps=50, log_to_wandb=False)
+    cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=0 if args.sae else L, optimizer=args.optimizer, lr=2e-4,
+                      lr_warmup_steps=50, log_to_wandb=False, force_lr_warmup=args.optimizer == "signum")
     act_dtype = torch.bfloat16 if args.dtype == "bfloat16" else torch.float32
     es = 2 if args.dtype == "bfloat16" else 4
 
@@ -268,7 +270,7 @@ def main():
             "host_issue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": f"GPT-2 small CLT: {L} layers, cross_layer={L}, d={d}, latents={M}, k={k}, "
-                                   f"skip_connection, {args.dtype} weights, Adam{'' if args.activation == 'topk' else ', ' + args.activation}; {N} tokens/step/GPU "
+                                   f"skip_connection, {args.dtype} weights, {'Adam' if args.optimizer == 'adam' else 'SignSGD'}{'' if args.activation == 'topk' else ', ' + args.activation}; {N} tokens/step/GPU "
                                    f"(BASELINE.json configs[1])",
                        "tokens_per_step": tokens_per_step, "params_per_gpu": P_total, "parallelism": parallelism},
             "fvu_last": round(float(sum(float(v) for v in fv.values()) / len(fv)), 5),

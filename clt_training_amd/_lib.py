@@ -71,6 +71,7 @@ SIGNATURES = {
     "clt_fvu_partial": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "clt_fvu_grad": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _vp, _f32, _vp, _vp, _i32, _vp]),
     "clt_adam_step": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "clt_signsgd_step": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp]),
 }
 
 _lib = None

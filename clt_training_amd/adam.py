@@ -21,6 +21,8 @@ CHUNK = int(os.environ.get("CLT_ADAM_CHUNK", 1 << 14))  # elements per workgroup
 
 
 class Adam(torch.optim.Optimizer):
+    HAS_STATE = True
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         defaults = dict(lr=lr, betas=betas, eps=eps)
         super().__init__(params, defaults)
@@ -79,8 +81,6 @@ class Adam(torch.optim.Optimizer):
                     live.append((gi, p))
         if not live:
             return
-        betas = self.param_groups[0]["betas"]
-        eps = self.param_groups[0]["eps"]
         dev = live[0][1].device
         key = tuple(id(p) for _, p in live)
         tb = self._tables.get(key)
@@ -111,15 +111,47 @@ class Adam(torch.optim.Optimizer):
             if not g.is_contiguous():
                 g = p.grad = g.contiguous()
             assert p.is_contiguous() and g.shape == p.shape
-            st = self._state(p)
             r = recs[ti]
-            r.p, r.g, r.m, r.v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            if self.HAS_STATE:
+                st = self._state(p)
+                r.p, r.g, r.m, r.v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            else:
+                r.p, r.g, r.m, r.v = p.data_ptr(), g.data_ptr(), None, None
             r.numel = p.numel()
             r.lr = float(self.param_groups[gi]["lr"])
             r.p_dtype, r.g_dtype = _DT[p.dtype], _DT[g.dtype]
         devt.copy_(host, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
-        _call("clt_adam_step", C.c_void_p(devt.data_ptr()), len(live), C.c_void_p(ct.data_ptr()),
+        self._launch(devt, len(live), ct, cs)
+
+    def _launch(self, devt, n_tensors, ct, cs):
+        betas = self.param_groups[0]["betas"]
+        eps = self.param_groups[0]["eps"]
+        _call("clt_adam_step", C.c_void_p(devt.data_ptr()), n_tensors, C.c_void_p(ct.data_ptr()),
               C.c_void_p(cs.data_ptr()), ct.numel(), CHUNK, 1.0, float(betas[0]), float(betas[1]), float(eps),
               self._step, _stream(devt))
+
+
+class SignSGD(Adam):
+    """sparsify/sign_sgd.py:5-23 (steepest descent in the L-infinity norm): ``p -= lr * sign(p.grad)`` for every parameter
+    that has a gradient, all tensors in one launch of ``clt_signsgd_step``.  No optimizer state."""
+
+    HAS_STATE = False
+
+    def __init__(self, params, lr: float = 1e-3):
+        if lr <= 0.0:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        torch.optim.Optimizer.__init__(self, params, {"lr": lr})
+        self._step = 0
+        self._tables = {}
+
+    def fused_rows(self, p):  # no fused row-pass form: the gradient kernels write plain gradients for this optimizer
+        return None
+
+    def fused_rows_by_ptr(self, ptr):
+        return None
+
+    def _launch(self, devt, n_tensors, ct, cs):
+        _call("clt_signsgd_step", C.c_void_p(devt.data_ptr()), n_tensors, C.c_void_p(ct.data_ptr()),
+              C.c_void_p(cs.data_ptr()), ct.numel(), CHUNK, 1.0, _stream(devt))

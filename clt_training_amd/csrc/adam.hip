@@ -107,9 +107,83 @@ __global__ __launch_bounds__(256) void adam_kernel(const clt_adam_tensor* __rest
   }
 }
 
+// SignSGD (sparsify/sign_sgd.py:19-23): p -= lr * sign(g); sign(0) = 0, so a parameter whose gradient is zero keeps its
+// bits.  HBM-bound: one read of p and g, one write of p.
+template <typename PT, typename GT>
+__device__ __forceinline__ void signsgd_chunk(PT* __restrict__ p, const GT* __restrict__ g, int64_t n, float lr) {
+  constexpr int V = 8;
+  const int64_t nvec = n / V;
+#pragma unroll 2
+  for (int64_t i = threadIdx.x; i < nvec; i += 256) {
+    float pf[V], gf[V];
+    if constexpr (sizeof(PT) == 2) {
+      nt_load8(p + i * V, pf);
+    } else {
+      float a[4], b[4];
+      Chunk<float>::load(p + i * V, a); Chunk<float>::load(p + i * V + 4, b);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pf[q] = a[q], pf[q + 4] = b[q];
+    }
+    if constexpr (sizeof(GT) == 2) {
+      nt_load8(g + i * V, gf);
+    } else {
+      float a[4], b[4];
+      Chunk<float>::load(g + i * V, a); Chunk<float>::load(g + i * V + 4, b);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gf[q] = a[q], gf[q + 4] = b[q];
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const float sgn = gf[q] > 0.f ? 1.f : (gf[q] < 0.f ? -1.f : gf[q]);  // +-0 -> 0 (and a NaN gradient stays NaN)
+      pf[q] = fmaf(-lr, sgn, pf[q]);                                       // Tensor.add_(sign, alpha=-lr)
+    }
+    if constexpr (sizeof(PT) == 2) {
+      nt_store8(p + i * V, pf);
+    } else {
+      *reinterpret_cast<float4*>(p + i * V) = make_float4(pf[0], pf[1], pf[2], pf[3]);
+      *reinterpret_cast<float4*>(p + i * V + 4) = make_float4(pf[4], pf[5], pf[6], pf[7]);
+    }
+  }
+  for (int64_t i = nvec * V + threadIdx.x; i < n; i += 256) {
+    const float gf = (float)g[i];
+    const float sgn = gf > 0.f ? 1.f : (gf < 0.f ? -1.f : gf);
+    p[i] = (PT)fmaf(-lr, sgn, (float)p[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void signsgd_kernel(const clt_adam_tensor* __restrict__ tensors,
+                                                      const int32_t* __restrict__ chunk_tensor,
+                                                      const int64_t* __restrict__ chunk_start, int chunk_elems,
+                                                      float lr_factor) {
+  const clt_adam_tensor t = tensors[chunk_tensor[blockIdx.x]];
+  const int64_t start = chunk_start[blockIdx.x];
+  const int64_t n = min((int64_t)chunk_elems, t.numel - start);
+  if (n <= 0) return;
+  const float lr = t.lr * lr_factor;
+  if (t.p_dtype == CLT_BF16) {
+    if (t.g_dtype == CLT_BF16) signsgd_chunk((bf16_t*)t.p + start, (const bf16_t*)t.g + start, n, lr);
+    else signsgd_chunk((bf16_t*)t.p + start, (const float*)t.g + start, n, lr);
+  } else {
+    if (t.g_dtype == CLT_BF16) signsgd_chunk((float*)t.p + start, (const bf16_t*)t.g + start, n, lr);
+    else signsgd_chunk((float*)t.p + start, (const float*)t.g + start, n, lr);
+  }
+}
+
 }  // namespace clt
 
 using namespace clt;
+
+extern "C" int clt_signsgd_step(const clt_adam_tensor* tensors, int n_tensors, const int32_t* chunk_tensor,
+                                const int64_t* chunk_start, int64_t n_chunks, int chunk_elems, float lr_factor,
+                                clt_stream_t stream) {
+  CLT_CHECK_ARG(tensors && chunk_tensor && chunk_start, "clt_signsgd_step: null pointer");
+  CLT_CHECK_ARG(n_tensors > 0 && n_chunks > 0 && n_chunks < (1ll << 31), "clt_signsgd_step: bad sizes");
+  CLT_CHECK_ARG(chunk_elems > 0 && chunk_elems % 8 == 0, "clt_signsgd_step: chunk_elems must be a positive multiple of 8");
+  hipLaunchKernelGGL(signsgd_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunk_tensor,
+                     chunk_start, chunk_elems, lr_factor);
+  CLT_CHECK_LAUNCH("clt_signsgd_step");
+  return CLT_OK;
+}
 
 extern "C" int clt_adam_step(const clt_adam_tensor* tensors, int n_tensors, const int32_t* chunk_tensor,
                              const int64_t* chunk_start, int64_t n_chunks, int chunk_elems, float lr_factor, float b1,

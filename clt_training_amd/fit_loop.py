@@ -11,6 +11,21 @@ import torch
 import torch.distributed as dist
 
 
+class WarmupLinearSchedule(torch.optim.lr_scheduler.LambdaLR):
+    """trainer.py:45-58."""
+
+    def __init__(self, optimizer, warmup_steps, num_training_steps):
+        self.warmup_steps = warmup_steps
+        self.num_training_steps = num_training_steps
+        super().__init__(optimizer, self.lr_lambda, last_epoch=-1)
+
+    def lr_lambda(self, current_step):
+        if current_step < self.warmup_steps:
+            return float(current_step) / float(max(1, self.warmup_steps))
+        return max(0.0, float(self.num_training_steps - current_step)
+                   / float(max(1, self.num_training_steps - self.warmup_steps)))
+
+
 class FitLoop:
     # set by the trainers: cfg, dataset, model, saes, num_tokens_since_fired, global_step, step(), save()
     wandb_log: Optional[Callable[[dict, int], None]] = None  # ``wandb.log``-shaped sink for the reference's keys
@@ -27,6 +42,34 @@ class FitLoop:
         widths = resolve_widths(model, cfg.hookpoints)
         acts = ModelActivations(model, dataset, cfg)
         return acts, widths, len(acts), model.device
+
+    # ------------------------------------------------------------------ optimizers (trainer.py:151-254)
+    @staticmethod
+    def build_optimizers(cfg, param_lists, num_latents, num_batches, adam_cls=None, signsgd_cls=None):
+        """One parameter group per sparse coder with the reference's LR rule; -> (optimizers, lr_schedulers)."""
+        if cfg.optimizer in ("adam", "adam8"):
+            if cfg.optimizer == "adam8":  # trainer.py:155-164: torchao's AdamW8bit when importable, else plain Adam
+                print("torchao 8-bit Adam not available, using Adam")
+            if adam_cls is None:
+                from .adam import Adam as adam_cls
+            pgs = [dict(params=ps, lr=torch.tensor(cfg.lr or 2e-4 / (m / (2**14)) ** 0.5))  # trainer.py:166-173
+                   for ps, m in zip(param_lists, num_latents)]
+            opt = adam_cls(pgs, betas=(cfg.b1, cfg.b2))
+        elif cfg.optimizer == "signum":
+            if not cfg.force_lr_warmup:
+                # trainer.py:234-242 wraps SignSGD in schedulefree.ScheduleFreeWrapper(momentum=0.95); that package is
+                # a third-party dependency absent from the reference tree and from this image: nothing to pin it on.
+                raise NotImplementedError("optimizer='signum' needs force_lr_warmup=True here (plain SignSGD + linear "
+                                          "warm-up, trainer.py:239-250); the ScheduleFree wrapper is not built")
+            if signsgd_cls is None:
+                from .adam import SignSGD as signsgd_cls
+            pgs = [dict(params=ps, lr=cfg.lr or 5e-3 / (m / (2**14)) ** 0.5)  # trainer.py:225-231
+                   for ps, m in zip(param_lists, num_latents)]
+            opt = signsgd_cls(pgs)
+        else:
+            raise NotImplementedError(f"optimizer {cfg.optimizer!r} is not on the MI355X hot path")
+        # get_linear_schedule_with_warmup (trainer.py:246-250) is the same lambda as WarmupLinearSchedule (:45-58)
+        return [opt], [WarmupLinearSchedule(opt, cfg.lr_warmup_steps, num_batches)]
 
     # ------------------------------------------------------------------ k schedule
     def init_k_schedule(self):

@@ -17,15 +17,14 @@ from .adam import Adam
 from .config import TrainConfig
 from .engine import CLTEngine, Comm, ShardedCoder
 from .fit_loop import FitLoop
-from .trainer import WarmupLinearSchedule
 
 
 class TPTrainer(FitLoop):
     def __init__(self, cfg: TrainConfig, dataset, model=None, mesh=None, *, device="cuda",
                  input_widths: Optional[dict] = None, num_batches: Optional[int] = None, ops=None, group=None,
                  optimizer_cls=None, coders: Optional[list] = None, comm: Optional[Comm] = None):
-        if cfg.optimizer not in ("adam", "adam8") or cfg.loss_fn != "fvu":  # adam8 without torchao = Adam (:155-164)
-            raise NotImplementedError("only optimizer='adam', loss_fn='fvu' are on the MI355X hot path")
+        if cfg.loss_fn != "fvu":
+            raise NotImplementedError("only loss_fn='fvu' is on the MI355X hot path")
         if model is not None:  # frozen HF model + token rows: every rank feeds its own shard of the sequences
             dataset, input_widths, num_batches, device = self.attach_model(cfg, dataset, model)
         assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
@@ -59,18 +58,18 @@ class TPTrainer(FitLoop):
         self.engine = CLTEngine(cfg, [self.saes[h] for h in cfg.hookpoints], ops, self.comm)
         if num_batches is None:
             num_batches = len(dataset)
-        pgs = [dict(params=[p for p in sae.parameters() if p.requires_grad],
-                    lr=torch.tensor(cfg.lr or 2e-4 / (sae.num_latents / (2**14)) ** 0.5))
-               for sae in self.saes.values()]  # trainer.py:166-173: the FULL latent count sets the LR
-        adam = (optimizer_cls or Adam)(pgs, betas=(cfg.b1, cfg.b2))
-        self.optimizers = [adam]
+        # trainer.py:166-173: the FULL latent count sets the LR
+        self.optimizers, self.lr_schedulers = self.build_optimizers(
+            cfg, [[p for p in sae.parameters() if p.requires_grad] for sae in self.saes.values()],
+            [sae.num_latents for sae in self.saes.values()], num_batches, adam_cls=optimizer_cls,
+            signsgd_cls=getattr(ops, "SignSGD", None))
+        opt = self.optimizers[0]
         # Decoder / encoder row gradients go straight into the optimizer update (no .grad round trip) when nothing
-        # else consumes them: one micro-step per optimizer step, and no projection of the decoder gradient.
+        # else consumes them: one micro-step per optimizer step, and an optimizer that has the fused form (Adam).
         # (a unit-norm SAE decoder's gradient projection happens inside the same row pass: engine.layer_step)
-        fuse = (hasattr(adam, "fused_rows") and cfg.grad_acc_steps * cfg.micro_acc_steps == 1
-                and not os.environ.get("CLT_NO_FUSED_ADAM"))
-        self.engine.fused_opt = adam if fuse else None
-        self.lr_schedulers = [WarmupLinearSchedule(adam, cfg.lr_warmup_steps, num_batches)]
+        fuse = (cfg.optimizer in ("adam", "adam8") and hasattr(opt, "fused_rows")
+                and cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and not os.environ.get("CLT_NO_FUSED_ADAM"))
+        self.engine.fused_opt = opt if fuse else None
         self.global_step = 0
         self.num_tokens_since_fired = {h: torch.zeros(s.m_local, device=self.device, dtype=torch.long)
                                        for h, s in self.saes.items()}

@@ -19,24 +19,9 @@ from torch import Tensor
 from . import fused_state
 from .adam import Adam
 from .config import TrainConfig
-from .fit_loop import FitLoop
+from .fit_loop import FitLoop, WarmupLinearSchedule  # noqa: F401 (re-exported)
 from .runner import CrossLayerRunner
 from .sparse_coder import SparseCoder
-
-
-class WarmupLinearSchedule(torch.optim.lr_scheduler.LambdaLR):
-    """trainer.py:45-58."""
-
-    def __init__(self, optimizer, warmup_steps, num_training_steps):
-        self.warmup_steps = warmup_steps
-        self.num_training_steps = num_training_steps
-        super().__init__(optimizer, self.lr_lambda, last_epoch=-1)
-
-    def lr_lambda(self, current_step):
-        if current_step < self.warmup_steps:
-            return float(current_step) / float(max(1, self.warmup_steps))
-        return max(0.0, float(self.num_training_steps - current_step)
-                   / float(max(1, self.num_training_steps - self.warmup_steps)))
 
 
 class Trainer(FitLoop):
@@ -53,10 +38,6 @@ class Trainer(FitLoop):
                  input_widths: Optional[dict] = None, num_batches: Optional[int] = None):
         if mesh is not None:
             raise NotImplementedError("use clt_training_amd.tp for latent sharding over RCCL")
-        if cfg.optimizer == "adam8":  # trainer.py:155-164: torchao's 8-bit Adam when importable, else plain Adam
-            print("torchao 8-bit Adam not available, using Adam")
-        elif cfg.optimizer != "adam":
-            raise NotImplementedError("only optimizer='adam' is on the MI355X hot path")
         if model is not None:
             dataset, input_widths, num_batches, device = self.attach_model(cfg, dataset, model)
         assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
@@ -92,16 +73,14 @@ class Trainer(FitLoop):
 
         if num_batches is None:
             num_batches = len(dataset)
-        # ---- optimizer (trainer.py:166-193)
-        pgs = [dict(params=list(sae.parameters()),
-                    lr=torch.tensor(cfg.lr or 2e-4 / (sae.num_latents / (2**14)) ** 0.5))
-               for sae in self.saes.values()]
-        adam = Adam(pgs, betas=(cfg.b1, cfg.b2))
-        self.optimizers = [adam]
-        self.lr_schedulers = [WarmupLinearSchedule(adam, cfg.lr_warmup_steps, num_batches)]
+        # ---- optimizer (trainer.py:151-254)
+        self.optimizers, self.lr_schedulers = self.build_optimizers(
+            cfg, [list(sae.parameters()) for sae in self.saes.values()],
+            [sae.num_latents for sae in self.saes.values()], num_batches)
         # Row gradients of the [M, d] matrices go straight into the Adam update inside the gradient kernels when each
         # optimizer step sees one micro-step (fused_state): no dense .grad, no second pass over the tables.
-        self._fused = (cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and not os.environ.get("CLT_NO_FUSED_ADAM"))
+        self._fused = (cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and not os.environ.get("CLT_NO_FUSED_ADAM")
+                       and type(self.optimizers[0]) is Adam)
         if self._fused:
             for sae in self.saes.values():
                 if sae.cfg.normalize_decoder and not cfg.sae.transcode:

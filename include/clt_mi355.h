@@ -290,6 +290,12 @@ int clt_adam_step(const clt_adam_tensor* tensors, int n_tensors, const int32_t* 
                   const int64_t* chunk_start, int64_t n_chunks, int chunk_elems, float lr_factor, float b1,
                   float b2, float eps, int step, clt_stream_t stream);
 
+/* SignSGD (sparsify/sign_sgd.py:19-23, the update under optimizer="signum"): p -= lr * lr_factor * sign(g) for
+ * every tensor of the table (m and v of the records are ignored and may be NULL); sign(0) = 0.  */
+int clt_signsgd_step(const clt_adam_tensor* tensors, int n_tensors, const int32_t* chunk_tensor,
+                     const int64_t* chunk_start, int64_t n_chunks, int chunk_elems, float lr_factor,
+                     clt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

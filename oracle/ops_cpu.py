@@ -191,3 +191,20 @@ def fvu_grad(y, yhat, mask, l2tv, gscale=1.0, g_dtype=None):
 
 class Adam(torch.optim.Adam):
     """torch.optim.Adam stands in for the HIP multi-tensor Adam in CPU tests."""
+
+
+class SignSGD(torch.optim.Optimizer):
+    """sparsify/sign_sgd.py:5-23 restated (``p -= lr * sign(p.grad)``): the CPU double of clt_signsgd_step."""
+
+    def __init__(self, params, lr: float = 1e-3):
+        if lr <= 0.0:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        super().__init__(params, {"lr": lr})
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None, "Closure is not supported."
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    p.add_(p.grad.sign(), alpha=-group["lr"])

@@ -360,3 +360,55 @@ def test_model_driven_fit_and_resume(which, tmp_path):
     got = params(tr4)
     for n in want:
         torch.testing.assert_close(got[n], want[n], rtol=0, atol=0, msg=n)
+
+
+def test_trainer_signum_hip_equals_torch_signsgd(monkeypatch):
+    """optimizer="signum" with force_lr_warmup (trainer.py:224-250): three bf16 CLT steps with the HIP SignSGD against the
+    same trainer stepping with the torch restatement of sign_sgd.py on the same (HIP-computed) gradients: bit for bit.
+    Without force_lr_warmup the reference wraps it in ScheduleFree (third-party, absent): that must raise."""
+    from clt_training_amd import SparseCoderConfig, TrainConfig, Trainer
+    from clt_training_amd import adam as adam_mod
+    from oracle import ops_cpu
+
+    d, N, k, L = 64, 512, 8, 3
+    hooks = [f"h.{i}" for i in range(L)]
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for s_ in range(3):
+        b = {}
+        for h in hooks:
+            x = torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)
+            b[h] = (x.bfloat16().to(DEV), (0.5 * x + 0.5 * torch.randn(N, d, generator=g)).bfloat16().to(DEV))
+        batches.append(b)
+
+    def make_cfg(**kw):
+        return TrainConfig(sae=SparseCoderConfig(dtype="bfloat16", expansion_factor=32, k=k, transcode=True,
+                                                 skip_connection=True), hookpoints=list(hooks), cross_layer=L,
+                           optimizer="signum", lr_warmup_steps=2, log_to_wandb=False, **kw)
+
+    with pytest.raises(NotImplementedError, match="force_lr_warmup"):
+        Trainer(make_cfg(), batches, device=DEV, num_batches=10)
+
+    def run(torch_double):
+        if torch_double:
+            monkeypatch.setattr(adam_mod, "SignSGD", ops_cpu.SignSGD)
+        torch.manual_seed(0)
+        tr = Trainer(make_cfg(force_lr_warmup=True), batches, device=DEV, num_batches=10)
+        assert not tr._fused and type(tr.optimizers[0]).__name__ == "SignSGD"
+        # trainer.py:225-231: 5e-3 / sqrt(M / 2^14) per group, a float
+        assert abs(tr.optimizers[0].param_groups[0]["initial_lr"] - 5e-3 / (d * 32 / 2**14) ** 0.5) < 1e-12
+        with torch.no_grad():
+            gg = torch.Generator(device=DEV).manual_seed(1)
+            for sae in tr.saes.values():
+                for n, p in sae.named_parameters():
+                    if n.startswith("W_dec"):
+                        p.copy_((0.05 * torch.randn(p.shape, generator=gg, device=DEV)).to(p.dtype))
+        fv = [{h: float(v) for h, v in tr.step(b).items()} for b in batches]
+        return fv, {f"{h}.{n}": p.detach().clone() for h, sae in tr.saes.items() for n, p in sae.named_parameters()}
+
+    fv_a, pa = run(False)
+    fv_b, pb = run(True)
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
+    assert fv_a == fv_b
+    assert fv_a[2]["h.2"] < fv_a[0]["h.2"] or fv_a[2]["h.0"] < fv_a[0]["h.0"]  # and it trains

@@ -659,3 +659,31 @@ def test_encode_groupmax_bf16_layer_shape(ops):
     assert bool((i // (M // k) == torch.arange(k, device=DEV)).all())   # one column per group, in group order
     first = torch.where(pre.view(N, k, -1) == rv.unsqueeze(-1), torch.arange(M // k, device=DEV), M).min(-1).values
     assert torch.equal(i, first + torch.arange(0, M, M // k, device=DEV))  # and it is the FIRST maximum
+
+
+# ----------------------------------------------------------------------------- SignSGD (sign_sgd.py:19-23)
+@pytest.mark.parametrize("pdt", [torch.float32, torch.bfloat16])
+def test_signsgd_step_equals_torch(pdt):
+    """clt_signsgd_step over a table of tensors (vector body, scalar tail, several chunks, a tensor without a gradient,
+    zero gradients) against ``p.add_(p.grad.sign(), alpha=-lr)``: bit for bit."""
+    from clt_training_amd.adam import SignSGD
+
+    g = torch.Generator().manual_seed(0)
+    shapes = [(50_000,), (7,), (129, 33), (1,), (4096, 8)]
+    ps = [torch.randn(s, generator=g).to(pdt).to(DEV).requires_grad_() for s in shapes]
+    lrs = [3e-3, 1e-2]
+    opt = SignSGD([dict(params=ps[:3], lr=lrs[0]), dict(params=ps[3:], lr=lrs[1])])
+    for step in range(3):
+        want = []
+        for i, p in enumerate(ps):
+            if i == 1 and step == 1:
+                p.grad = None
+                want.append(p.detach().clone())
+                continue
+            gr = torch.randn(p.shape, generator=g).to(pdt)  # (torch ties a .grad to the parameter's dtype)
+            gr[gr.abs() < 0.3] = 0  # sign(0) = 0: those parameters keep their bits
+            p.grad = gr.to(DEV)
+            want.append(p.detach().clone().add_(p.grad.sign(), alpha=-lrs[0 if i < 3 else 1]))
+        opt.step()
+        for p, w in zip(ps, want):
+            assert torch.equal(p.detach(), w)

@@ -72,7 +72,7 @@ def _oracle_layers(saes):
     return layers
 
 
-def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir, device="cpu", resume=False):
+def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir, device="cpu", resume=False, train_kw=None):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -91,8 +91,8 @@ def _worker(rank, world, port, sae_kw, L, cross, d, N, out_dir, device="cpu", re
     saes, steps = _make_problem(sae_kw, L, cross, d, N)
     hooks = [f"h.{i}" for i in range(L)]
     from clt_training_amd import SparseCoderConfig
-    cfg = TrainConfig(sae=SparseCoderConfig(**sae_kw), hookpoints=hooks, cross_layer=cross, optimizer="adam", lr=1e-2,
-                      lr_warmup_steps=2, finetune="skip-step0-init")
+    cfg = TrainConfig(**{**dict(sae=SparseCoderConfig(**sae_kw), hookpoints=hooks, cross_layer=cross, optimizer="adam",
+                              lr=1e-2, lr_warmup_steps=2, finetune="skip-step0-init"), **(train_kw or {})})
     coders = [ShardedCoder.from_full(s, rank, world, device) for s in saes]
     tr = TPTrainer(cfg, [None] * 4, device=device, input_widths={h: d for h in hooks}, ops=ops,
                    optimizer_cls=adam_cls, coders=coders)
@@ -134,16 +134,21 @@ CASES = {
     "sae": (dict(transcode=False, expansion_factor=4, k=4, normalize_decoder=False), 1, 0),
     # fused_encoder.py:373-413: each shard owns k / tp whole groups; the exchange is a concatenation
     "clt_groupmax": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True, activation="groupmax"), 3, 3),
+    # optimizer="signum" with force_lr_warmup: SignSGD (sign_sgd.py:19-23) + the linear warm-up (trainer.py:224-250)
+    "clt_signum": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True), 3, 2,
+                   dict(optimizer="signum", force_lr_warmup=True, lr=1e-3)),
 }
 
 
 def run_case(case, tmp_path, device="cpu", resume=False):
     from oracle import clt_oracle as O
 
-    sae_kw, L, cross = CASES[case]
+    sae_kw, L, cross, *rest = CASES[case]
+    train_kw = rest[0] if rest else {}
     d, N, world = 16, 24, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, sae_kw, L, cross, d, N, str(tmp_path), device, resume), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, sae_kw, L, cross, d, N, str(tmp_path), device, resume, train_kw), nprocs=world,
+             join=True)
     res = [torch.load(f"{tmp_path}/rank{r}.pt", weights_only=True) for r in range(world)]
     # ---- single-process oracle: 3 steps of clt_train_step + Adam with the warm-up schedule
     saes, steps = _make_problem(sae_kw, L, cross, d, N)
@@ -157,7 +162,7 @@ def run_case(case, tmp_path, device="cpu", resume=False):
                              divide_cross_layer=sae_kw.get("divide_cross_layer", False),
                              activation=sae_kw.get("activation", "topk"))
         want_fvu.append([float(f) for f in r.fvus])
-        lr = 1e-2 * O.warmup_linear_factor(s, 2, 4)
+        lr = train_kw.get("lr", 1e-2) * O.warmup_linear_factor(s, 2, 4)
         for l, lp in enumerate(layers):
             tensors = {"W_enc": lp.W_enc, "b_enc": lp.b_enc}
             for i in range(len(lp.W_decs)):
@@ -169,6 +174,9 @@ def run_case(case, tmp_path, device="cpu", resume=False):
                 if lp.post_enc_scales is not None:
                     tensors[f"post_enc_scales.{i}"] = lp.post_enc_scales[i]
             for n, p in tensors.items():
+                if train_kw.get("optimizer") == "signum":
+                    p.sub_(lr * torch.sign(r.grads[l][n].float()))  # sign_sgd.py:23
+                    continue
                 mm, vv = state[l].get(n, (torch.zeros_like(p).double(), torch.zeros_like(p).double()))
                 pn, mm, vv = O.adam_step(p, r.grads[l][n], mm, vv, s + 1, lr)
                 p.copy_(pn.float())
