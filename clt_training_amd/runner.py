@@ -1,8 +1,7 @@
 """CrossLayerRunner: mirror of sparsify/runner.py:11-201 for the coalescing modes on the
 hot path -- ``coalesce_topk="none"`` (every live source layer decodes into the current
-target with its own W_decs[j - i], runner.py:60-71) and ``"concat"`` with
-``topk_coalesced=False`` (per-target tied decoder over the concatenated candidates,
-runner.py:93-127).  Same bookkeeping: insertion-ordered live sources, deferred encoder
+target with its own W_decs[j - i], runner.py:60-71) and ``"concat"`` (per-target tied decoder over
+the concatenated candidates, or with ``topk_coalesced`` over their k best, runner.py:93-127).  Same bookkeeping: insertion-ordered live sources, deferred encoder
 backward (``restore``) for the sources that just wrote their last target."""
 from __future__ import annotations
 
@@ -23,10 +22,8 @@ class CrossLayerRunner(object):
     def decode(self, mid_out: MidDecoder, y: Tensor, module_name: str, detach_grad: bool = False,
                advance: bool = True, **kwargs):
         cfg = mid_out.sparse_coder.cfg
-        if cfg.secondary_target_tied or cfg.coalesce_topk in ("per-layer", "group") or (
-                cfg.do_coalesce_topk and cfg.topk_coalesced):
-            raise NotImplementedError("only coalesce_topk in {'none', 'concat'} with topk_coalesced=False "
-                                      "is on the MI355X hot path")
+        if cfg.secondary_target_tied or cfg.coalesce_topk in ("per-layer", "group"):
+            raise NotImplementedError("only coalesce_topk in {'none', 'concat'} is on the MI355X hot path")
         self.outputs[module_name] = mid_out
 
         candidate_indices, candidate_values, layer_mids = [], [], []
@@ -59,9 +56,12 @@ class CrossLayerRunner(object):
             else:
                 layer_mid.next()
 
-        if cfg.do_coalesce_topk:  # "concat", topk_coalesced=False (runner.py:118-127)
+        if cfg.do_coalesce_topk:  # "concat" (runner.py:93-127)
             best_indices = torch.cat(candidate_indices, dim=1)
             best_values = torch.cat(candidate_values, dim=1)
+            if cfg.topk_coalesced:  # runner.py:96-117: the k best of the [N, k * n_live] candidates (a small torch op;
+                best_values, pos = torch.topk(best_values, k=cfg.k, dim=1)  # autograd routes the gradient back)
+                best_indices = torch.gather(best_indices, 1, pos)
             new_mid_out = mid_out.copy(indices=best_indices, activations=best_values)
             out = new_mid_out(y, index=0, add_post_enc=False, **kwargs)
             if advance:

@@ -366,6 +366,7 @@ def clt_train_step(
     act_dtype=None,
     forced_idx: Optional[list] = None,
     activation: str = "topk",
+    topk_coalesced: bool = False,
 ) -> StepResult:
     """Explicit forward+backward of one FVU train step over all layers, in the
     order the reference's hook runs them (trainer.py:598-682): for each layer j
@@ -453,6 +454,11 @@ def clt_train_step(
                 ci.append(st["idx"])  # (idx + pos*M) % M == idx, runner.py:53,122
             cat_v = torch.cat(cv, 1)
             cat_i = torch.cat(ci, 1)
+            sel = None
+            if topk_coalesced:  # runner.py:96-117: keep the k best of the concatenated candidates
+                full_v = cat_v
+                sel = torch.sort(cat_v, dim=1, descending=True, stable=True).indices[:, :k]
+                cat_v, cat_i = cat_v.gather(1, sel), cat_i.gather(1, sel)
             sae_out = (lp.W_decs[0].to(dt)[cat_i] * cat_v.unsqueeze(-1)).sum(1) + lp.b_decs[0].to(dt)
             if lp.W_skips[0] is not None:
                 sae_out = sae_out + xn @ lp.W_skips[0].to(dt).T
@@ -496,6 +502,8 @@ def clt_train_step(
                 0, cat_i.reshape(-1), G.repeat_interleave(kk, 0) * cat_v.reshape(-1, 1))
             grads[j]["W_decs.0"] += gW
             ga_cat = (lp.W_decs[0].to(dt)[cat_i] * G.unsqueeze(1)).sum(-1)
+            if sel is not None:  # torch.topk backward: the gradient goes to the selected positions only
+                ga_cat = torch.zeros_like(full_v).scatter_(1, sel, ga_cat)
             off = 0
             for i in live:
                 st = state[i]

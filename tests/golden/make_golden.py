@@ -274,6 +274,11 @@ def main(only=None):
                       dict(expansion_factor=8, k=8, transcode=True, skip_connection=True, activation="groupmax"),
                       N=40, d=32, seed=13, masked=True)
         return
+    if only == "topk_coalesced":
+        golden_clt("clt_concat_topkcoal_L3",
+                   dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, coalesce_topk="concat",
+                        topk_coalesced=True, post_encoder_scale=True), L=3, cross=3, N=28, d=24, seed=14)
+        return
     golden_encoder("encoder_a", N=32, d=48, M=512, k=8, seed=1)
     golden_encoder("encoder_b", N=16, d=64, M=256, k=32, seed=2)
     golden_decoder("decoder_d48", N=2, d=48, M=128, k=10, seed=3)  # tests/test_decode.py shapes

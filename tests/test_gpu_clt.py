@@ -93,7 +93,7 @@ def test_single_layer_vs_reference_golden(name, fp32_exact):
         torch.testing.assert_close(sae.W_dec.grad.cpu(), t["g_proj.W_dec"], rtol=1e-5, atol=2e-7)
 
 
-@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3"])
+@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3", "clt_concat_topkcoal_L3"])
 def test_clt_vs_reference_golden(name, fp32_exact):
     t, meta = load_golden(name)
     L = meta["L"]

@@ -54,6 +54,7 @@ def _check_step(t, meta, layers, xs, ys, mask, single):
         normalize_io=cfg.get("normalize_io", False),
         divide_cross_layer=cfg.get("divide_cross_layer", False),
         activation=cfg.get("activation", "topk"),
+        topk_coalesced=cfg.get("topk_coalesced", False),
     )
     for l in range(len(layers)):
         sfx = "" if single else f".{l}"
@@ -90,7 +91,7 @@ def test_single_layer_golden(name):
         torch.testing.assert_close(W, layers[0].W_decs[0], **FP32)  # golden was unit-normed already
 
 
-@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3"])
+@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3", "clt_concat_topkcoal_L3"])
 def test_clt_golden(name):
     t, meta = load_golden(name)
     L = meta["L"]
