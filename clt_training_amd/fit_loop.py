@@ -43,6 +43,16 @@ class FitLoop:
         acts = ModelActivations(model, dataset, cfg)
         return acts, widths, len(acts), model.device
 
+    @staticmethod
+    def check_supported(cfg):
+        """Configurations the hot path does not implement fail loudly instead of training something else."""
+        if cfg.loss_fn != "fvu":  # trainer.py:739-780: the end-to-end losses run the SAE inside the model forward
+            raise NotImplementedError("only loss_fn='fvu' is on the MI355X hot path")
+        if cfg.dead_latent_penalty > 0.0:  # trainer.py:653-676 (DeadLatentLoss)
+            raise NotImplementedError("dead_latent_penalty > 0 (DeadLatentLoss) is not built")
+        if len(cfg.init_seeds) != 1:  # (the reference's hook looks SAEs up by module name only, trainer.py:513-515, 544)
+            raise NotImplementedError("one init seed per run")
+
     # ------------------------------------------------------------------ optimizers (trainer.py:151-254)
     @staticmethod
     def build_optimizers(cfg, param_lists, num_latents, num_batches, adam_cls=None, signsgd_cls=None):

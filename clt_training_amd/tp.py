@@ -23,8 +23,7 @@ class TPTrainer(FitLoop):
     def __init__(self, cfg: TrainConfig, dataset, model=None, mesh=None, *, device="cuda",
                  input_widths: Optional[dict] = None, num_batches: Optional[int] = None, ops=None, group=None,
                  optimizer_cls=None, coders: Optional[list] = None, comm: Optional[Comm] = None):
-        if cfg.loss_fn != "fvu":
-            raise NotImplementedError("only loss_fn='fvu' is on the MI355X hot path")
+        self.check_supported(cfg)
         if model is not None:  # frozen HF model + token rows: every rank feeds its own shard of the sequences
             dataset, input_widths, num_batches, device = self.attach_model(cfg, dataset, model)
         assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"

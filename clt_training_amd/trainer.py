@@ -41,8 +41,7 @@ class Trainer(FitLoop):
         if model is not None:
             dataset, input_widths, num_batches, device = self.attach_model(cfg, dataset, model)
         assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
-        if cfg.loss_fn != "fvu":
-            raise NotImplementedError("only loss_fn='fvu' is on the MI355X hot path")
+        self.check_supported(cfg)
         cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
         self.cfg = cfg
         self.dataset = dataset
