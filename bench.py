@@ -123,8 +123,8 @@ def main():
     ap.add_argument("--sae", action="store_true",
                     help="plain SAE per hookpoint (no transcoding, no skip, unit-norm decoder): BASELINE configs[3] shape "
                          "with --layers 1 --d-model 4096 --expansion 32 --k 192; a secondary data point, not the metric")
-    ap.add_argument("--activation", default="topk", choices=["topk", "groupmax"],
-                    help="groupmax (fused_encoder.py:373-413) is a secondary data point, not the metric")
+    ap.add_argument("--activation", default="topk", choices=["topk", "groupmax", "batchtopk"],
+                    help="groupmax / batchtopk (fused_encoder.py:373-413 / 204-240) are secondary data points, not the metric")
     ap.add_argument("--optimizer", default="adam", choices=["adam", "signum"],
                     help="signum = SignSGD + linear warm-up (force_lr_warmup); a secondary data point, not the metric")
     ap.add_argument("--simulate-tp", type=int, default=0,

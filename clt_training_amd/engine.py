@@ -378,11 +378,16 @@ class CLTEngine:
                 win = comm.all_gather_cat1(packed)
                 v, idx = (win >> 32).to(torch.int32).view(torch.float32).to(cd), win & 0xFFFFFFFF
         else:
-            if cfg.activation != "topk":
+            if cfg.activation not in ("topk", "batchtopk"):
                 raise NotImplementedError(f"activation {cfg.activation!r}")
-            v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, k, out_dtype=cd)
+            kk = 4 * k if cfg.activation == "batchtopk" else k  # fused_encoder.py:315-318: row top-4k first
+            v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, kk, out_dtype=cd)
             if comm.world > 1:
-                v, idx = self._merge_candidates(v, idx + lp.lat_begin, k)
+                v, idx = self._merge_candidates(v, idx + lp.lat_begin, kk)
+            if cfg.activation == "batchtopk":
+                # the batch-wide threshold of fused_encoder.py:204-240 on the MERGED rows (the single-device rule; every
+                # rank holds the same [N, 4k] and takes the same threshold)
+                v = ops.batch_threshold(v, k)
         return dict(xn_r=self._keep_input(j, xn_r.to(cd)), x_enc=x_enc, v=v, idx=idx)
 
     @torch.no_grad()
@@ -396,7 +401,7 @@ class CLTEngine:
         if enc is None:
             enc = self.encode_part(j, x_r, y_r)
         x_enc, v, idx = enc["x_enc"], enc["v"], enc["idx"]
-        N = x_enc.shape[0]
+        N, k = v.shape  # (4 * cfg.k slots per row under batchtopk)
         me = _Live(j, enc["xn_r"], x_enc, v, idx, torch.zeros(N, k, dtype=torch.float32, device=v.device))
         self.live.append(me)
         div = max(1, len(self.live) - 1) if cfg.divide_cross_layer else 1  # runner.py:46-49

@@ -69,15 +69,19 @@ def fused_encoder(input: Tensor, weight: Tensor, bias: Tensor, k: int,
                   activation: Literal["groupmax", "topk"] = "topk", use_fp8: bool = False) -> EncoderOutput:
     """input (N, D), weight (M, D), bias (M,) -> top-k (or, :373-413, groupmax) values / indices
     (fused_encoder.py:293-309)."""
-    if activation not in ("topk", "groupmax"):
-        raise NotImplementedError(f"activation {activation!r}: 'topk' and 'groupmax' are on the MI355X hot path")
+    if activation not in ("topk", "groupmax", "batchtopk"):
+        raise NotImplementedError(f"activation {activation!r}")
     if use_fp8:
         raise NotImplementedError("use_fp8 is out of scope (no BASELINE config uses it)")
     with torch.no_grad():
         cd = _compute_dtype(input, weight)
         x = input if input.dtype == cd else input.to(cd)
         W = weight if weight.dtype == cd else weight.to(cd)
-        values, indices = ops.encode_topk(x, W, bias, k, out_dtype=cd, activation=activation)
+        if activation == "batchtopk":  # fused_encoder.py:315-318, 204-240: row top-4k, then the batch-wide threshold
+            values, indices = ops.encode_topk(x, W, bias, 4 * k, out_dtype=cd)
+            values = ops.batch_threshold(values, k)
+        else:
+            values, indices = ops.encode_topk(x, W, bias, k, out_dtype=cd, activation=activation)
     indices._clt_seg = SegmentsHolder()
     values = FusedEncoder.apply(input, weight, bias, values, indices, activation)
     return EncoderOutput(top_acts=values, top_indices=indices)

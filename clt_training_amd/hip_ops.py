@@ -136,6 +136,15 @@ def groupmax_rows(vals: Tensor, k: int, out_dtype=None):
     return ov, oi
 
 
+def batch_threshold(v: Tensor, k: int) -> Tensor:
+    """batch_topk (fused_encoder.py:204-240) on the per-row top-4k values [N, 4k]: keep the k * N largest of the batch,
+    zero the rest (ties with the threshold survive, as ``preacts < threshold`` leaves them).  Small torch glue: one
+    selection over N * 4k values and one masked fill, no host sync."""
+    n = v.shape[0]
+    thr = torch.topk(v.flatten().float(), k * n, sorted=False).values.min()
+    return v.masked_fill(v.float() < thr, 0)
+
+
 def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=None, activation: str = "topk"):
     """relu(x W^T + b) -> row top-k (fused_encoder.py:310-322,372) or groupmax (:373-413)."""
     if activation not in ("topk", "groupmax"):

@@ -78,9 +78,23 @@ def groupmax(pre: Tensor, k: int):
     return vals.contiguous(), (first + torch.arange(0, m, gs)).contiguous()
 
 
+def batch_threshold(vals: Tensor, k: int) -> Tensor:
+    """batch_topk (fused_encoder.py:204-240, single device) on the per-row top-4k values ``vals [N, 4k]``: the k * N
+    largest of the whole batch survive, everything below the smallest of them becomes 0."""
+    n = vals.shape[0]
+    thr = torch.topk(vals.flatten(), k * n, sorted=False).values.min()
+    return torch.where(vals < thr, torch.zeros_like(vals), vals)
+
+
 def encoder_forward(x, W, b, k, out_dtype=None, activation="topk"):
-    """fused_encoder(..., activation) forward -- fused_encoder.py:310-322,372 ("topk"), :373-413 ("groupmax")."""
+    """fused_encoder(..., activation) forward -- fused_encoder.py:310-322,372 ("topk"), :373-413 ("groupmax"),
+    :315-318 + 204-240 ("batchtopk": [N, 4k] outputs; the zeroed slots keep the index they had in the row's top-4k --
+    the reference leaves those to torch.topk's order among equal zeros, and nothing downstream reads them: their
+    activation is 0 and FusedEncoder.backward masks their gradient, fused_encoder.py:97)."""
     pre = encoder_preacts(x, W, b, out_dtype)
+    if activation == "batchtopk":
+        v, i = topk_lowest_index(pre, 4 * k)
+        return batch_threshold(v, k), i
     return topk_lowest_index(pre, k) if activation == "topk" else groupmax(pre, k)
 
 
@@ -398,13 +412,14 @@ def clt_train_step(
     state = {}  # per live source: dict(xn, x_enc, v, idx, slot, gv_acc)
     fvus, accts, idxs, sae_outs = [], [], [], []
 
+    k_cfg = k
     for j in range(L):
         lp = layers[j]
         d = xs[j].shape[-1]
         xn = _normalize_in(lp, xs[j].to(dt), normalize_io)
         x_enc = xn if lp.transcode else xn - lp.b_decs[0].to(dt)  # sparse_coder.py:637-638
         if forced_idx is None:
-            v, idx = encoder_forward(x_enc, lp.W_enc.to(dt), lp.b_enc.to(dt), k, None, activation)
+            v, idx = encoder_forward(x_enc, lp.W_enc.to(dt), lp.b_enc.to(dt), k_cfg, None, activation)
         else:
             # reduced-precision parity: evaluate the step on a GIVEN selection (the near-tie order of a
             # bf16 GEMM is not reproducible across accumulation orders); validity of the selection is
@@ -415,6 +430,7 @@ def clt_train_step(
             v = round_to(v, act_dtype)
         accts.append(v.clone())
         idxs.append(idx.clone())
+        k = v.shape[1]  # batchtopk: 4k slots per row
         live.append(j)
         state[j] = dict(xn=xn, x_enc=x_enc, v=v, idx=idx, slot=0, gv=torch.zeros_like(v, dtype=dt))
 

@@ -22,6 +22,10 @@ def encode_topk(x, W, b, k, out_dtype=None, activation="topk"):
     return v.to(out_dtype), i
 
 
+def batch_threshold(v, k):
+    return O.batch_threshold(v.float(), k).to(v.dtype)
+
+
 def groupmax_rows(vals, k, out_dtype=None):
     v, i = O.groupmax(vals.float(), k)
     return v.to(out_dtype or vals.dtype), i

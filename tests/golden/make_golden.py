@@ -112,7 +112,7 @@ def golden_encoder(name, N, d, M, k, seed, activation="topk"):
     x = torch.randn(N, d, generator=g).requires_grad_()
     W = (torch.randn(M, d, generator=g) / d**0.5).requires_grad_()
     b = (0.1 * torch.randn(M, generator=g)).requires_grad_()
-    up = torch.randn(N, k, generator=g)
+    up = torch.randn(N, 4 * k if activation == "batchtopk" else k, generator=g)
     out = fused_encoder(x, W, b, k, activation)
     vals, idx = out.top_acts, out.top_indices
     # loss 1: sum of values (tests/test_encode.py:46)
@@ -273,6 +273,12 @@ def main(only=None):
         golden_single("single_transcoder_groupmax",
                       dict(expansion_factor=8, k=8, transcode=True, skip_connection=True, activation="groupmax"),
                       N=40, d=32, seed=13, masked=True)
+        return
+    if only == "batchtopk":
+        golden_encoder("encoder_batchtopk", N=24, d=48, M=512, k=4, seed=15, activation="batchtopk")
+        golden_single("single_transcoder_batchtopk",
+                      dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, activation="batchtopk"),
+                      N=40, d=32, seed=16, masked=True)
         return
     if only == "topk_coalesced":
         golden_clt("clt_concat_topkcoal_L3",

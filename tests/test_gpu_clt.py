@@ -65,7 +65,8 @@ def check_against_golden(t, saes, outs, encs, single):
     for l, sae in enumerate(saes):
         sfx = "" if single else f".{l}"
         v, i = O.topk_merge(encs[l][1].float().cpu(), encs[l][0].cpu(), encs[l][0].shape[1])
-        assert torch.equal(i, t[f"idx{sfx}"])  # bit-exact index sets
+        live = t[f"vals{sfx}"] > 0  # (batchtopk: the index of a zeroed slot is not defined by the reference)
+        assert torch.equal(v > 0, live) and torch.equal(i[live], t[f"idx{sfx}"][live])  # bit-exact index sets
         torch.testing.assert_close(v, t[f"vals{sfx}"], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(outs[l].sae_out.float().cpu(), t[f"sae_out{sfx}"], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(outs[l].fvu.float().cpu(), t[f"fvu{sfx}"], rtol=1e-5, atol=1e-6)
@@ -81,7 +82,7 @@ def check_against_golden(t, saes, outs, encs, single):
 
 
 @pytest.mark.parametrize("name", ["single_transcoder_skip", "single_transcoder_scale_norm", "single_sae",
-                                  "single_transcoder_groupmax"])
+                                  "single_transcoder_groupmax", "single_transcoder_batchtopk"])
 def test_single_layer_vs_reference_golden(name, fp32_exact):
     t, meta = load_golden(name)
     sae = build_sae(t, meta, 0, True)

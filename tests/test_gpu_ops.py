@@ -687,3 +687,26 @@ def test_signsgd_step_equals_torch(pdt):
         opt.step()
         for p, w in zip(ps, want):
             assert torch.equal(p.detach(), w)
+
+
+def test_encode_batchtopk_vs_reference_golden(ops):
+    """activation="batchtopk" (fused_encoder.py:204-240, 315-318) through the autograd seam against the golden from the
+    reference's own fused_encoder: [N, 4k] outputs, k * N positive survivors, indices bit-exact where the activation is
+    positive (the reference leaves the index of a zeroed slot to torch.topk's order among equal zeros), grads rtol 1e-5."""
+    from clt_training_amd.fused_encoder import fused_encoder
+
+    t, meta = load_golden("encoder_batchtopk")
+    k = meta["k"]
+    for tag in ("sum", "up"):
+        x, W, b = (t[n].to(DEV).requires_grad_() for n in ("x", "W", "b"))
+        out = fused_encoder(x, W, b, k, "batchtopk")
+        v, i = out.top_acts.detach().cpu(), out.top_indices.cpu()
+        assert v.shape == (meta["N"], 4 * k) and int((v > 0).sum()) == k * meta["N"]
+        live = t["vals"] > 0
+        torch.testing.assert_close(v, t["vals"], **FP32)
+        assert torch.equal(v > 0, live) and torch.equal(i[live], t["idx"][live])
+        up = torch.ones_like(out.top_acts) if tag == "sum" else t["up"].to(DEV)
+        (out.top_acts * up).sum().backward()
+        torch.testing.assert_close(W.grad.cpu(), t[f"gW_{tag}"], **FP32)
+        torch.testing.assert_close(b.grad.cpu(), t[f"gb_{tag}"], **FP32)
+        torch.testing.assert_close(x.grad.cpu(), t[f"gx_{tag}"], **FP32)

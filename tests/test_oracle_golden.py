@@ -13,13 +13,25 @@ def scatter_up(t):
     return t["up"]
 
 
-@pytest.mark.parametrize("name", ["encoder_a", "encoder_b", "encoder_groupmax"])
+def assert_same_selection(got_v, got_i, ref_v, ref_i):
+    """Values to rtol 1e-5; indices bit-exact wherever the activation is positive (batchtopk zeroes slots whose index
+    the reference leaves to torch.topk's order among equal zeros; their activation and gradient are 0)."""
+    torch.testing.assert_close(got_v, ref_v, **FP32)
+    live = ref_v > 0
+    assert torch.equal(got_v > 0, live)
+    assert torch.equal(got_i[live], ref_i[live])
+    if bool(live.all()):
+        assert torch.equal(got_i, ref_i)
+
+
+@pytest.mark.parametrize("name", ["encoder_a", "encoder_b", "encoder_groupmax", "encoder_batchtopk"])
 def test_encoder_golden(name):
     t, meta = load_golden(name)
     k = meta["k"]
     vals, idx = O.encoder_forward(t["x"], t["W"], t["b"], k, activation=meta.get("activation", "topk"))
-    assert torch.equal(idx, t["idx"])  # bit-exact index sets, canonical order
-    torch.testing.assert_close(vals, t["vals"], **FP32)
+    assert_same_selection(vals, idx, t["vals"], t["idx"])  # bit-exact index sets, canonical order
+    if meta.get("activation") == "batchtopk":
+        assert vals.shape[1] == 4 * k and int((vals > 0).sum()) == k * vals.shape[0]  # k * N survivors in the batch
     for tag, g in (("sum", torch.ones_like(vals)), ("up", t["up"])):
         gW, gb, gx, _ = O.encoder_backward(t["x"], t["W"], vals, idx, g, need_grad_x=True)
         torch.testing.assert_close(gW, t[f"gW_{tag}"], **FP32)
@@ -61,8 +73,7 @@ def _check_step(t, meta, layers, xs, ys, mask, single):
         got_v, got_i = res.top_acts[l].float(), res.top_idx[l]
         if cfg.get("activation") == "groupmax":  # group order -> the goldens' canonical (value desc, index asc) order
             got_v, got_i = O.topk_merge(got_v, got_i, got_v.shape[1])
-        assert torch.equal(got_i, t[f"idx{sfx}"])
-        torch.testing.assert_close(got_v, t[f"vals{sfx}"], **FP32)
+        assert_same_selection(got_v, got_i, t[f"vals{sfx}"], t[f"idx{sfx}"])
         torch.testing.assert_close(res.sae_outs[l], t[f"sae_out{sfx}"], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(res.fvus[l], t[f"fvu{sfx}"], **FP32)
         gpre = "g." if single else f"g.{l}."
@@ -79,7 +90,7 @@ def _check_step(t, meta, layers, xs, ys, mask, single):
 
 
 @pytest.mark.parametrize("name", ["single_transcoder_skip", "single_transcoder_scale_norm", "single_sae",
-                                  "single_transcoder_groupmax"])
+                                  "single_transcoder_groupmax", "single_transcoder_batchtopk"])
 def test_single_layer_golden(name):
     t, meta = load_golden(name)
     layers = golden_layers(t, meta)

@@ -134,6 +134,8 @@ CASES = {
     "sae": (dict(transcode=False, expansion_factor=4, k=4, normalize_decoder=False), 1, 0),
     # fused_encoder.py:373-413: each shard owns k / tp whole groups; the exchange is a concatenation
     "clt_groupmax": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True, activation="groupmax"), 3, 3),
+    # fused_encoder.py:204-240, 315-318: row top-4k, merge, batch-wide threshold on the merged rows
+    "clt_batchtopk": (dict(transcode=True, expansion_factor=4, k=2, skip_connection=True, activation="batchtopk"), 3, 2),
     # optimizer="signum" with force_lr_warmup: SignSGD (sign_sgd.py:19-23) + the linear warm-up (trainer.py:224-250)
     "clt_signum": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True), 3, 2,
                    dict(optimizer="signum", force_lr_warmup=True, lr=1e-3)),
