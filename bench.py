@@ -108,8 +108,8 @@ def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tokens", type=int, default=8192, help="tokens per step per GPU")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--d-model", type=int, default=768)
