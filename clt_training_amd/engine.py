@@ -29,7 +29,6 @@ under gloo.
 """
 from __future__ import annotations
 
-import math
 import os
 from dataclasses import dataclass, field
 from typing import Optional

@@ -13,7 +13,6 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from .adam import Adam
 from .config import TrainConfig
 from .engine import CLTEngine, Comm, ShardedCoder
 from .fit_loop import FitLoop

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import os
 from dataclasses import replace
-from typing import Callable, Iterable, Optional
+from typing import Optional
 
 import torch
 from torch import Tensor

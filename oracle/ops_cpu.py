@@ -3,7 +3,6 @@ TEST INFRASTRUCTURE ONLY: lets the CPU tests drive the sharding / collective log
 ``clt_training_amd.engine`` under gloo.  Never imported by the product."""
 from __future__ import annotations
 
-from typing import Optional
 
 import torch
 
