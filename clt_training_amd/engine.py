@@ -367,6 +367,7 @@ class CLTEngine:
         xn_r = x_r.float() * (d**0.5 / lp.in_norm) if cfg.normalize_io else x_r
         x_enc_r = xn_r if cfg.transcode else xn_r.float() - lp.b_decs[0]
         x_enc = comm.all_gather_rows(x_enc_r.to(cd))
+        fired = None
         if cfg.activation == "groupmax":
             # fused_encoder.py:373-413: the k groups are runs of consecutive latents, so each shard owns k / tp whole
             # groups and the exchange is a plain concatenation (one all-gather of value bits | global index)
@@ -387,7 +388,11 @@ class CLTEngine:
                 # the batch-wide threshold of fused_encoder.py:204-240 on the MERGED rows (the single-device rule; every
                 # rank holds the same [N, 4k] and takes the same threshold)
                 v = ops.batch_threshold(v, k)
-        return dict(xn_r=self._keep_input(j, xn_r.to(cd)), x_enc=x_enc, v=v, idx=idx)
+                # The zeroed slots (3 of 4) carry nothing forward or backward: hand the kernels an out-of-range index for
+                # them, which the segment builder and the decode kernels drop like another shard's entries.  The
+                # fired-latent bookkeeping keeps the indices as the reference would mark them (trainer.py:622-628).
+                fired, idx = idx, torch.where(v > 0, idx, torch.full_like(idx, -1))
+        return dict(xn_r=self._keep_input(j, xn_r.to(cd)), x_enc=x_enc, v=v, idx=idx, fired=fired)
 
     @torch.no_grad()
     def layer_step(self, j: int, x_r: Tensor, y_r: Tensor, mask_r: Optional[Tensor], acc_steps: int = 1,
@@ -565,7 +570,7 @@ class CLTEngine:
                 still.append(st)
         self.live = still
         self.last_fvu[j] = fvu
-        self.last_idx[j] = idx  # merged global indices (fired-latent bookkeeping, trainer.py:622-628)
+        self.last_idx[j] = idx if enc.get("fired") is None else enc["fired"]  # merged global indices (trainer.py:622-628)
         return fvu
 
     def _fused_state(self, p: Tensor, acc_steps: int):

@@ -127,7 +127,8 @@ class TPTrainer(FitLoop):
                 enc, ev = pending.pop(j)
                 main.wait_event(ev)
                 for t in enc.values():
-                    t.record_stream(main)  # allocated on the side stream, consumed (and released) on this one
+                    if t is not None:
+                        t.record_stream(main)  # allocated on the side stream, consumed (and released) on this one
             self.last_fvu[name] = eng.layer_step(j, x, y, mask, acc_steps, enc=enc)
             # fired-latent bookkeeping on this rank's latent range (trainer.py:622-628)
             loc = eng.last_idx[j].flatten() - sae.lat_begin
