@@ -1,9 +1,12 @@
 """CrossLayerRunner: mirror of sparsify/runner.py:11-201 for the coalescing modes on the
 hot path -- ``coalesce_topk="none"`` (every live source layer decodes into the current
 target with its own W_decs[j - i], runner.py:60-71) and ``"concat"`` (per-target tied decoder over
-the concatenated candidates, or with ``topk_coalesced`` over their k best, runner.py:93-127).  Same bookkeeping: insertion-ordered live sources, deferred encoder
+the concatenated candidates, or with ``topk_coalesced`` over their k best, runner.py:93-127) and
+``"per-layer"`` (the target's decoder holds one block of rows per live source, runner.py:130-158).  Same bookkeeping: insertion-ordered live sources, deferred encoder
 backward (``restore``) for the sources that just wrote their last target."""
 from __future__ import annotations
+
+from dataclasses import replace
 
 import torch
 from torch import Tensor
@@ -22,8 +25,8 @@ class CrossLayerRunner(object):
     def decode(self, mid_out: MidDecoder, y: Tensor, module_name: str, detach_grad: bool = False,
                advance: bool = True, **kwargs):
         cfg = mid_out.sparse_coder.cfg
-        if cfg.secondary_target_tied or cfg.coalesce_topk in ("per-layer", "group"):
-            raise NotImplementedError("only coalesce_topk in {'none', 'concat'} is on the MI355X hot path")
+        if cfg.secondary_target_tied or cfg.coalesce_topk == "group":
+            raise NotImplementedError("coalesce_topk in {'none', 'concat', 'per-layer'} is built")
         self.outputs[module_name] = mid_out
 
         candidate_indices, candidate_values, layer_mids = [], [], []
@@ -36,8 +39,11 @@ class CrossLayerRunner(object):
             divide_by = max(1, len(self.outputs) - 1) if layer_mid.sparse_coder.cfg.divide_cross_layer else 1
             layer_mids.append(layer_mid)
             if cfg.do_coalesce_topk:
-                # (idx + i*M) % M == idx (runner.py:53,122): the offset only matters to per-layer mode
-                candidate_indices.append(layer_mid.latent_indices)
+                # runner.py:52-54: candidates carry their position among the live sources.  "concat" takes it off
+                # again ((idx + i*M) % M == idx, :122); "per-layer" decodes with it: the target's W_dec holds one
+                # block of M rows per live source (sparse_coder.py:306-307)
+                off = i * layer_mid.sparse_coder.num_latents if cfg.coalesce_topk == "per-layer" else 0
+                candidate_indices.append(layer_mid.latent_indices + off if off else layer_mid.latent_indices)
                 candidate_values.append(layer_mid.current_latent_acts)
             if detach_grad and advance:
                 self.to_restore[hookpoint] = (layer_mid, layer_mid.will_be_last)
@@ -64,8 +70,12 @@ class CrossLayerRunner(object):
                 best_indices = torch.gather(best_indices, 1, pos)
             new_mid_out = mid_out.copy(indices=best_indices, activations=best_values)
             out = new_mid_out(y, index=0, add_post_enc=False, **kwargs)
-            if advance:
-                del mid_out.x
+            if cfg.coalesce_topk == "concat":
+                if advance:
+                    del mid_out.x
+            else:  # "per-layer" (runner.py:130-158): report the current layer's own latents, 0 elsewhere
+                M = mid_out.sparse_coder.num_latents
+                out = replace(out, latent_indices=(out.latent_indices % M) * (out.latent_indices // M == i))
 
         assert hookpoint == module_name  # last output guaranteed to be the current layer
         if not advance:

@@ -388,7 +388,7 @@ def clt_train_step(
     deferred encoder backward of the sources that just wrote their last target
     (runner.py:56-59, 193-197).
 
-    ``coalesce`` in {"none", "concat"} (runner.py:60-73 vs :93-127).
+    ``coalesce`` in {"none", "concat", "per-layer"} (runner.py:60-73 vs :93-127 vs :130-158).
     Returns per-layer FVU and the gradient of every parameter, computed with the
     closed forms of SURVEY.md section 9 -- no autograd.
     """
@@ -457,9 +457,9 @@ def clt_train_step(
                     addition = addition + out  # runner.py:70-71
                 else:
                     sae_out = out + addition / divide_by  # runner.py:63, sparse_coder.py:191
-        elif coalesce == "concat":
+        elif coalesce in ("concat", "per-layer"):
             cv, ci = [], []
-            for i in live:
+            for pos, i in enumerate(live):
                 st = state[i]
                 li = layers[i]
                 t = st["slot"]
@@ -467,7 +467,9 @@ def clt_train_step(
                 a = post_affine_fwd(st["v"], st["idx"], li.post_encs[t].to(dt), scale)
                 per_src[i] = dict(a=a, t=t)
                 cv.append(a)
-                ci.append(st["idx"])  # (idx + pos*M) % M == idx, runner.py:53,122
+                # runner.py:52-54: idx + pos * M; "concat" takes it off again (% M, :122), "per-layer" decodes with
+                # it (the target's W_dec has one block of M rows per live source, sparse_coder.py:306-307)
+                ci.append(st["idx"] + pos * li.W_enc.shape[0] if coalesce == "per-layer" else st["idx"])
             cat_v = torch.cat(cv, 1)
             cat_i = torch.cat(ci, 1)
             sel = None

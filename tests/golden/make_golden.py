@@ -280,6 +280,11 @@ def main(only=None):
                       dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, activation="batchtopk"),
                       N=40, d=32, seed=16, masked=True)
         return
+    if only == "per_layer":
+        golden_clt("clt_perlayer_L3",
+                   dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, coalesce_topk="per-layer",
+                        post_encoder_scale=True), L=3, cross=3, N=28, d=24, seed=17)
+        return
     if only == "topk_coalesced":
         golden_clt("clt_concat_topkcoal_L3",
                    dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, coalesce_topk="concat",

@@ -19,6 +19,8 @@ def build_sae(t, meta, l, single, dtype=torch.float32, cfg_over=None):
     cfgd = dict(meta["cfg"])
     if not single:
         cfgd["n_targets"] = min(meta["cross_layer"], meta["L"] - l)
+        # trainer.py:125-131: sources still listed at position l (p + n_targets(p) >= l, as the reference counts them)
+        cfgd["n_sources"] = sum(1 for p in range(l + 1) if p + min(meta["cross_layer"], meta["L"] - p) >= l)
     cfgd.update(cfg_over or {})
     cfg = SparseCoderConfig(**cfgd)
     sae = SparseCoder(meta["d"], cfg, DEV, dtype=torch.float32)
@@ -94,7 +96,8 @@ def test_single_layer_vs_reference_golden(name, fp32_exact):
         torch.testing.assert_close(sae.W_dec.grad.cpu(), t["g_proj.W_dec"], rtol=1e-5, atol=2e-7)
 
 
-@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3", "clt_concat_topkcoal_L3"])
+@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3", "clt_concat_topkcoal_L3",
+                                  "clt_perlayer_L3"])
 def test_clt_vs_reference_golden(name, fp32_exact):
     t, meta = load_golden(name)
     L = meta["L"]

@@ -102,7 +102,8 @@ def test_single_layer_golden(name):
         torch.testing.assert_close(W, layers[0].W_decs[0], **FP32)  # golden was unit-normed already
 
 
-@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3", "clt_concat_topkcoal_L3"])
+@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3", "clt_concat_topkcoal_L3",
+                                  "clt_perlayer_L3"])
 def test_clt_golden(name):
     t, meta = load_golden(name)
     L = meta["L"]
