@@ -79,7 +79,9 @@ class Trainer(FitLoop):
         # Row gradients of the [M, d] matrices go straight into the Adam update inside the gradient kernels when each
         # optimizer step sees one micro-step (fused_state): no dense .grad, no second pass over the tables.
         self._fused = (cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and not os.environ.get("CLT_NO_FUSED_ADAM")
-                       and type(self.optimizers[0]) is Adam)
+                       and type(self.optimizers[0]) is Adam
+                       # a decoder shared by several targets is read again after its first local backward
+                       and not cfg.sae.per_source_tied)
         if self._fused:
             for sae in self.saes.values():
                 if sae.cfg.normalize_decoder and not cfg.sae.transcode:

@@ -399,6 +399,7 @@ def clt_train_step(
         g = {"W_enc": torch.zeros_like(lp.W_enc, dtype=dt), "b_enc": torch.zeros_like(lp.b_enc, dtype=dt)}
         for t in range(len(lp.W_decs)):
             g[f"W_decs.{t}"] = torch.zeros_like(lp.W_decs[t], dtype=dt)
+        for t in range(len(lp.b_decs)):  # (per_source_tied: one W_dec, but a bias / skip matrix per target)
             g[f"b_decs.{t}"] = torch.zeros_like(lp.b_decs[t], dtype=dt)
             if lp.W_skips[t] is not None:
                 g[f"W_skips.{t}"] = torch.zeros_like(lp.W_skips[t], dtype=dt)
@@ -448,7 +449,8 @@ def clt_train_step(
                 t = st["slot"]
                 scale = None if li.post_enc_scales is None else li.post_enc_scales[t].to(dt)
                 a = post_affine_fwd(st["v"], st["idx"], li.post_encs[t].to(dt), scale)
-                out = (li.W_decs[t].to(dt)[st["idx"]] * a.unsqueeze(-1)).sum(1)  # sparse_coder.py:660
+                tw = t if t < len(li.W_decs) else 0  # per_source_tied: one decoder for all targets (sparse_coder.py:324-338)
+                out = (li.W_decs[tw].to(dt)[st["idx"]] * a.unsqueeze(-1)).sum(1)  # sparse_coder.py:660
                 out = out + li.b_decs[t].to(dt)  # sparse_coder.py:661
                 if li.W_skips[t] is not None:
                     out = out + st["xn"] @ li.W_skips[t].to(dt).T  # :190
@@ -501,10 +503,11 @@ def clt_train_step(
                 grads[i][f"b_decs.{t}"] += Gi.sum(0)
                 if li.W_skips[t] is not None:
                     grads[i][f"W_skips.{t}"] += Gi.T @ st["xn"]
-                gW = torch.zeros_like(grads[i][f"W_decs.{t}"]).index_add_(
+                tw = t if t < len(li.W_decs) else 0
+                gW = torch.zeros_like(grads[i][f"W_decs.{tw}"]).index_add_(
                     0, st["idx"].reshape(-1), Gi.repeat_interleave(k, 0) * a.reshape(-1, 1))
-                ga = (li.W_decs[t].to(dt)[st["idx"]] * Gi.unsqueeze(1)).sum(-1)
-                grads[i][f"W_decs.{t}"] += gW
+                ga = (li.W_decs[tw].to(dt)[st["idx"]] * Gi.unsqueeze(1)).sum(-1)
+                grads[i][f"W_decs.{tw}"] += gW
                 scale = None if li.post_enc_scales is None else li.post_enc_scales[t].to(dt)
                 u, gp, gs = post_affine_bwd(st["v"], st["idx"], li.post_encs[t].to(dt), scale, ga)
                 grads[i][f"post_encs.{t}"] += gp

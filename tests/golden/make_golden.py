@@ -285,6 +285,11 @@ def main(only=None):
                    dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, coalesce_topk="per-layer",
                         post_encoder_scale=True), L=3, cross=3, N=28, d=24, seed=17)
         return
+    if only == "per_source_tied":
+        golden_clt("clt_none_per_source_tied_L3",
+                   dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, per_source_tied=True,
+                        post_encoder_scale=True), L=3, cross=3, N=28, d=24, seed=18)
+        return
     if only == "topk_coalesced":
         golden_clt("clt_concat_topkcoal_L3",
                    dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, coalesce_topk="concat",

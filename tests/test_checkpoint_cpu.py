@@ -59,3 +59,21 @@ def test_sharded_coder_gathers_into_the_unsharded_file(tmp_path):
     half = ShardedCoder.load_from_disk(tmp_path / "s", "cpu", rank=1, tp=2)
     assert torch.equal(half.W_enc, sae.encoder.weight[32:]) and torch.equal(half.W_decs[1], sae.W_decs[1][32:])
     assert torch.equal(half.b_decs[1], sae.b_decs[1]) and half.lat_begin == 32
+
+
+def test_trainer_does_not_fuse_adam_into_a_tied_decoder():
+    """per_source_tied (sparse_coder.py:324-338): one W_dec serves every target of a source, and the hook-by-hook local
+    backward (trainer.py:674-682) would update it between two of its forward uses if the Adam step were applied inside
+    the gradient kernel.  The trainer must leave such runs to .grad -> Adam.step."""
+    import torch
+
+    from clt_training_amd import SparseCoderConfig, TrainConfig, Trainer
+
+    hooks = ["h.0", "h.1"]
+    data = [{h: (torch.zeros(4, 16), torch.zeros(4, 16)) for h in hooks}]
+    for tied in (False, True):
+        cfg = TrainConfig(sae=SparseCoderConfig(transcode=True, expansion_factor=2, k=2, per_source_tied=tied),
+                          hookpoints=list(hooks), cross_layer=2, optimizer="adam", log_to_wandb=False)
+        tr = Trainer(cfg, data, device="cpu")
+        assert tr._fused == (not tied)
+        assert hasattr(tr.saes["h.0"], "W_decs") == (not tied)
