@@ -25,7 +25,7 @@ class CrossLayerRunner(object):
     def decode(self, mid_out: MidDecoder, y: Tensor, module_name: str, detach_grad: bool = False,
                advance: bool = True, **kwargs):
         cfg = mid_out.sparse_coder.cfg
-        if cfg.secondary_target_tied or cfg.coalesce_topk == "group":
+        if cfg.coalesce_topk == "group" or (cfg.secondary_target_tied and cfg.do_coalesce_topk):
             raise NotImplementedError("coalesce_topk in {'none', 'concat', 'per-layer'} is built")
         self.outputs[module_name] = mid_out
 
@@ -38,7 +38,7 @@ class CrossLayerRunner(object):
                 layer_mid.detach()
             divide_by = max(1, len(self.outputs) - 1) if layer_mid.sparse_coder.cfg.divide_cross_layer else 1
             layer_mids.append(layer_mid)
-            if cfg.do_coalesce_topk:
+            if cfg.do_coalesce_topk or cfg.secondary_target_tied:
                 # runner.py:52-54: candidates carry their position among the live sources.  "concat" takes it off
                 # again ((idx + i*M) % M == idx, :122); "per-layer" decodes with it: the target's W_dec holds one
                 # block of M rows per live source (sparse_coder.py:306-307)
@@ -53,14 +53,20 @@ class CrossLayerRunner(object):
                 out = layer_mid(
                     y,
                     addition=(0 if hookpoint != module_name else (output / divide_by)),
-                    no_extras=(hookpoint != module_name),
-                    denormalize=(hookpoint == module_name),
+                    no_extras=(hookpoint != module_name) or cfg.secondary_target_tied,
+                    denormalize=(hookpoint == module_name) and not cfg.secondary_target_tied,
                     **kwargs,
                 )
                 if hookpoint != module_name:
                     output = output + out.sae_out
             else:
                 layer_mid.next()
+
+        if cfg.secondary_target_tied:  # runner.py:75-91: the current layer's slot-0 decoder also reads every candidate
+            new_mid_out = mid_out.copy(indices=torch.cat(candidate_indices, dim=1),
+                                       activations=torch.cat(candidate_values, dim=1))
+            out = new_mid_out(y, index=0, add_post_enc=False, no_extras=False, denormalize=True, addition=out.sae_out,
+                              **kwargs)
 
         if cfg.do_coalesce_topk:  # "concat" (runner.py:93-127)
             best_indices = torch.cat(candidate_indices, dim=1)

@@ -381,6 +381,7 @@ def clt_train_step(
     forced_idx: Optional[list] = None,
     activation: str = "topk",
     topk_coalesced: bool = False,
+    secondary_target_tied: bool = False,
 ) -> StepResult:
     """Explicit forward+backward of one FVU train step over all layers, in the
     order the reference's hook runs them (trainer.py:598-682): for each layer j
@@ -459,6 +460,14 @@ def clt_train_step(
                     addition = addition + out  # runner.py:70-71
                 else:
                     sae_out = out + addition / divide_by  # runner.py:63, sparse_coder.py:191
+            if secondary_target_tied:
+                # runner.py:75-91: a second decode of ALL candidates (post-affine values, indices mod M) through the
+                # current layer's slot-0 decoder, with its bias and skip once more, on top of the sum above
+                cat_v2 = torch.cat([per_src[i]["a"] for i in live], 1)
+                cat_i2 = torch.cat([state[i]["idx"] for i in live], 1)
+                sae_out = sae_out + (lp.W_decs[0].to(dt)[cat_i2] * cat_v2.unsqueeze(-1)).sum(1) + lp.b_decs[0].to(dt)
+                if lp.W_skips[0] is not None:
+                    sae_out = sae_out + xn @ lp.W_skips[0].to(dt).T
         elif coalesce in ("concat", "per-layer"):
             cv, ci = [], []
             for pos, i in enumerate(live):
@@ -494,7 +503,16 @@ def clt_train_step(
         # ---------------- backward of fvu / acc_steps ----------------
         G = fvu_bwd(e, tv, mask, 1.0 / acc_steps) * denorm  # grad wrt pre-denormalised sum
         if coalesce == "none":
-            for i in live:
+            ga2 = None
+            if secondary_target_tied:
+                grads[j]["b_decs.0"] += G.sum(0)
+                if lp.W_skips[0] is not None:
+                    grads[j]["W_skips.0"] += G.T @ xn
+                kk2 = cat_i2.shape[1]
+                grads[j]["W_decs.0"] += torch.zeros_like(grads[j]["W_decs.0"]).index_add_(
+                    0, cat_i2.reshape(-1), G.repeat_interleave(kk2, 0) * cat_v2.reshape(-1, 1))
+                ga2 = (lp.W_decs[0].to(dt)[cat_i2] * G.unsqueeze(1)).sum(-1)
+            for pos, i in enumerate(live):
                 st = state[i]
                 li = layers[i]
                 t = per_src[i]["t"]
@@ -507,6 +525,8 @@ def clt_train_step(
                 gW = torch.zeros_like(grads[i][f"W_decs.{tw}"]).index_add_(
                     0, st["idx"].reshape(-1), Gi.repeat_interleave(k, 0) * a.reshape(-1, 1))
                 ga = (li.W_decs[tw].to(dt)[st["idx"]] * Gi.unsqueeze(1)).sum(-1)
+                if ga2 is not None:
+                    ga = ga + ga2[:, pos * k:(pos + 1) * k]
                 grads[i][f"W_decs.{tw}"] += gW
                 scale = None if li.post_enc_scales is None else li.post_enc_scales[t].to(dt)
                 u, gp, gs = post_affine_bwd(st["v"], st["idx"], li.post_encs[t].to(dt), scale, ga)

@@ -290,6 +290,11 @@ def main(only=None):
                    dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, per_source_tied=True,
                         post_encoder_scale=True), L=3, cross=3, N=28, d=24, seed=18)
         return
+    if only == "secondary_target_tied":
+        golden_clt("clt_none_secondary_tied_L3",
+                   dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, secondary_target_tied=True,
+                        post_encoder_scale=True, divide_cross_layer=True), L=3, cross=3, N=28, d=24, seed=19)
+        return
     if only == "topk_coalesced":
         golden_clt("clt_concat_topkcoal_L3",
                    dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, coalesce_topk="concat",

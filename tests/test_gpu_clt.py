@@ -97,7 +97,8 @@ def test_single_layer_vs_reference_golden(name, fp32_exact):
 
 
 @pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3", "clt_concat_topkcoal_L3",
-                                  "clt_perlayer_L3", "clt_none_per_source_tied_L3"])
+                                  "clt_perlayer_L3", "clt_none_per_source_tied_L3",
+                                  "clt_none_secondary_tied_L3"])
 def test_clt_vs_reference_golden(name, fp32_exact):
     t, meta = load_golden(name)
     L = meta["L"]

@@ -67,6 +67,7 @@ def _check_step(t, meta, layers, xs, ys, mask, single):
         divide_cross_layer=cfg.get("divide_cross_layer", False),
         activation=cfg.get("activation", "topk"),
         topk_coalesced=cfg.get("topk_coalesced", False),
+        secondary_target_tied=cfg.get("secondary_target_tied", False),
     )
     for l in range(len(layers)):
         sfx = "" if single else f".{l}"
@@ -103,7 +104,8 @@ def test_single_layer_golden(name):
 
 
 @pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3", "clt_concat_topkcoal_L3",
-                                  "clt_perlayer_L3", "clt_none_per_source_tied_L3"])
+                                  "clt_perlayer_L3", "clt_none_per_source_tied_L3",
+                                  "clt_none_secondary_tied_L3"])
 def test_clt_golden(name):
     t, meta = load_golden(name)
     L = meta["L"]
