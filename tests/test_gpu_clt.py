@@ -290,8 +290,9 @@ def test_trainer_fused_adam_equals_grad_then_adam(monkeypatch):
         assert fv_a == fv_b
 
 
+@pytest.mark.parametrize("kind", ["clt", "sae"])
 @pytest.mark.parametrize("which", ["autograd", "engine"])
-def test_model_driven_fit_and_resume(which, tmp_path):
+def test_model_driven_fit_and_resume(which, kind, tmp_path):
     """SURVEY.md section 8f rank 2 (trainer.py:73-111, 472-545, 684-692, 818-861, 275-354): a frozen random-init GPT-2
     drives ``fit`` through forward hooks; the parameters equal those of the same trainer fed the cached activations, and
     a run saved after two steps and resumed in a fresh trainer (``load_state`` + the dataset offset of :410-417) ends
@@ -316,12 +317,20 @@ def test_model_driven_fit_and_resume(which, tmp_path):
 
     rows = Rows({"input_ids": r} for r in ids)
 
+    # "sae": plain unit-norm autoencoders on the residual stream (block outputs are tuples: trainer.py:500-504), BOS
+    # filtered; the decoder's gradient projection and Adam update run inside the row pass
+    wild, names = (["h.*.mlp"], ["h.0.mlp", "h.1.mlp", "h.2.mlp"]) if kind == "clt" else (["h.[0-9]"], ["h.0", "h.1", "h.2"])
+
     def make(run, hooks):
         torch.manual_seed(0)
-        cfg = TrainConfig(sae=SparseCoderConfig(transcode=True, expansion_factor=8, k=8, skip_connection=True),
-                          hookpoints=hooks, cross_layer=3, optimizer="adam", lr=1e-2, lr_warmup_steps=2, batch_size=4,
-                          remove_first_token=True, log_to_wandb=False, save_dir=str(tmp_path), run_name=run, save_every=2)
-        return cfg
+        if kind == "clt":
+            sae = SparseCoderConfig(transcode=True, expansion_factor=8, k=8, skip_connection=True)
+            kw = dict(cross_layer=3, remove_first_token=True)
+        else:
+            sae = SparseCoderConfig(transcode=False, expansion_factor=8, k=8, normalize_decoder=True)
+            kw = dict(cross_layer=0, filter_bos=True)
+        return TrainConfig(sae=sae, hookpoints=hooks, optimizer="adam", lr=1e-2, lr_warmup_steps=2, batch_size=4,
+                           log_to_wandb=False, save_dir=str(tmp_path), run_name=run, save_every=2, **kw)
 
     def params(tr):
         return {f"{h}.{n}": p.detach().clone() for h, s in tr.saes.items() for n, p in s.named_parameters()}
@@ -331,18 +340,18 @@ def test_model_driven_fit_and_resume(which, tmp_path):
         with torch.no_grad():
             for s in tr.saes.values():
                 for n, p in s.named_parameters():
-                    if n.startswith("W_dec"):
+                    if n.startswith("W_dec") and kind == "clt":
                         p.copy_((0.1 * torch.randn(p.shape, generator=gg, device=DEV)).to(p.dtype))
 
     # ---- model-driven, 4 steps; checkpoints land after steps 1 and 3 (save_every=2: (step + 1) % 2 == 0 with step = 1, 3)
-    tr = cls(make("driven", ["h.*.mlp"]), rows, model)
+    tr = cls(make("driven", list(wild)), rows, model)
     warm(tr)
     tr.fit()
-    assert tr.global_step == 4 and tr.cfg.hookpoints == ["h.0.mlp", "h.1.mlp", "h.2.mlp"]
+    assert tr.global_step == 4 and tr.cfg.hookpoints == names
     want = params(tr)
 
     # ---- cached activations, the same 4 steps
-    cfg2 = make("cached", ["h.0.mlp", "h.1.mlp", "h.2.mlp"])
+    cfg2 = make("cached", list(names))
     cached = list(ModelActivations(model, rows, cfg2))
     tr2 = cls(cfg2, cached, device=DEV, num_batches=4)
     warm(tr2)
@@ -353,11 +362,11 @@ def test_model_driven_fit_and_resume(which, tmp_path):
         assert torch.equal(want[n], got[n]), n
 
     # ---- resume: one step, save, fresh trainer, load_state, fit the rest
-    tr3 = cls(make("resume", ["h.*.mlp"]), rows, model)
+    tr3 = cls(make("resume", list(wild)), rows, model)
     warm(tr3)
     tr3.step(next(iter(tr3.dataset)))
     tr3.save()
-    tr4 = cls(make("resume", ["h.*.mlp"]), rows, model)
+    tr4 = cls(make("resume", list(wild)), rows, model)
     tr4.load_state(f"{tmp_path}/resume")
     assert tr4.global_step == 1
     tr4.fit()
