@@ -309,7 +309,42 @@ class SparseCoder(nn.Module):
             else:
                 self.post_enc_scale = make_post_enc(is_zeros=False)
 
-    # ------------------------------------------------------------------ persistence (sparse_coder.py:505-612)
+    # ------------------------------------------------------------------ persistence (sparse_coder.py:448-612)
+    @staticmethod
+    def load_many(name: str, local: bool = False, layers: Optional[list] = None, device="cpu", *, decoder: bool = True,
+                  pattern: Optional[str] = None) -> dict:
+        """sparse_coder.py:448-479: one SparseCoder per hookpoint directory of a run (``local=True``: a directory on
+        disk; otherwise a Hub snapshot, which needs network access), in natural order."""
+        from fnmatch import fnmatch
+
+        from .activations import natural_key
+
+        pattern = pattern + "/*" if pattern is not None else None
+        if local:
+            repo_path = Path(name)
+        else:
+            from huggingface_hub import snapshot_download
+
+            repo_path = Path(snapshot_download(name, allow_patterns=pattern))
+        if layers is not None:
+            return {layer: SparseCoder.load_from_disk(repo_path / layer, device=device, decoder=decoder)
+                    for layer in sorted(layers, key=natural_key)}
+        files = [f for f in repo_path.iterdir() if f.is_dir() and (pattern is None or fnmatch(f.name, pattern))]
+        return {f.name: SparseCoder.load_from_disk(f, device=device, decoder=decoder)
+                for f in sorted(files, key=lambda f: natural_key(f.name))}
+
+    @staticmethod
+    def load_from_hub(name: str, hookpoint: Optional[str] = None, device="cpu", *, decoder: bool = True) -> "SparseCoder":
+        """sparse_coder.py:481-503 (needs network access)."""
+        from huggingface_hub import snapshot_download
+
+        repo_path = Path(snapshot_download(name, allow_patterns=f"{hookpoint}/*" if hookpoint is not None else None))
+        if hookpoint is not None:
+            repo_path = repo_path / hookpoint
+        elif not repo_path.joinpath("cfg.json").exists():
+            raise FileNotFoundError("No config file found; try specifying a layer.")
+        return SparseCoder.load_from_disk(repo_path, device=device, decoder=decoder)
+
     @staticmethod
     def load_from_disk(path, device="cpu", *, decoder: bool = True, mesh=None) -> "SparseCoder":
         from safetensors.torch import load_file

@@ -77,3 +77,22 @@ def test_trainer_does_not_fuse_adam_into_a_tied_decoder():
         tr = Trainer(cfg, data, device="cpu")
         assert tr._fused == (not tied)
         assert hasattr(tr.saes["h.0"], "W_decs") == (not tied)
+
+
+def test_load_many_local(tmp_path):
+    """sparse_coder.py:448-479: every hookpoint directory of a run, in natural order; ``layers`` selects."""
+    import torch
+
+    from clt_training_amd import SparseCoder, SparseCoderConfig
+
+    names = ["h.10.mlp", "h.2.mlp", "h.9.mlp"]
+    for i, n in enumerate(names):
+        torch.manual_seed(i)
+        SparseCoder(8, SparseCoderConfig(transcode=True, expansion_factor=2, k=2), "cpu", dtype=torch.float32).save_to_disk(tmp_path / n)
+    (tmp_path / "config.json").write_text("{}")  # a file beside the directories is not a hookpoint
+    got = SparseCoder.load_many(str(tmp_path), local=True)
+    assert list(got) == ["h.2.mlp", "h.9.mlp", "h.10.mlp"]
+    torch.manual_seed(1)
+    ref = SparseCoder(8, SparseCoderConfig(transcode=True, expansion_factor=2, k=2), "cpu", dtype=torch.float32)
+    assert torch.equal(got["h.2.mlp"].encoder.weight, ref.encoder.weight)
+    assert list(SparseCoder.load_many(str(tmp_path), local=True, layers=["h.9.mlp", "h.10.mlp"])) == ["h.9.mlp", "h.10.mlp"]
