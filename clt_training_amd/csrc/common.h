@@ -137,13 +137,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 // One element of torch.optim.Adam's update (trainer.py:178-186; exp_avg.lerp_, exp_avg_sq.mul_().addcmul_(),
 // param.addcdiv_()), written with explicit roundings: no contraction is left to the compiler, so every kernel that
 // applies it (clt_adam_step, clt_spt_dense_adam, clt_decode_bwd_rows_adam) produces the same bits.
+// The square root and the quotient are the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32: the correctly rounded forms hipcc
+// emits for sqrtf and '/' are ~10 instructions each, and the row passes are issue-bound (SQ counters).
+// The update term they feed is ~1e-3 of the parameter, so the parameter moves by < 1e-10 relative.
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float step_size, float b1, float b2,
                                             float inv_sqrt_bc2, float eps) {
 #pragma clang fp contract(off)
   m = fmaf(g - m, 1.f - b1, m);
   v = fmaf((1.f - b2) * g, g, b2 * v);
-  const float denom = fmaf(sqrtf(v), inv_sqrt_bc2, eps);
-  p = fmaf(-step_size, m / denom, p);
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_sqrt_bc2, eps);
+  p = fmaf(-step_size, m * __builtin_amdgcn_rcpf(denom), p);
 }
 
 // Wave sum without the LDS crossbar: four DPP row shifts leave each row-of-16 total in its lane 15, the four row
