@@ -8,6 +8,13 @@
 
 namespace clt {
 
+// Token of entry e = n * k + j.  k is a power of two in every BASELINE config: the shift replaces the ~25
+// instructions of an emulated 32-bit division (the row passes are issue-bound).  Wave-uniform branch.
+__device__ __forceinline__ int entry_token(int e, int k) {
+  return (k & (k - 1)) == 0 ? (e >> (31 - __clz(k))) : e / k;
+}
+
+
 template <typename OT, int E>
 __device__ __forceinline__ void store_row_chunk(OT* p, const float (&a)[E]) {
   if constexpr (sizeof(OT) == 2 && E == 8) {
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
       float w = vals[e];
       if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
       my_w = w;
-      my_n = e / k;
+      my_n = entry_token(e, k);
 #pragma unroll
       for (int q = 1; q < RW; ++q) my_row += pos >= bnd[q] ? 1 : 0;
     }
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(64) void rows_long_kernel(const int32_t* __restrict
         float w = vals[e];
         if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
         my_w = w;
-        my_n = e / k;
+        my_n = entry_token(e, k);
       }
       const int cnt = min(64, end - s0);
       for (int jj = 0; jj < cnt; jj += U) {
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds
       float w = vals[e];
       if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
       my_w = w;
-      my_n = e / k;
+      my_n = entry_token(e, k);
     }
     const int cnt = min(64, end - s0);
     for (int jj = 0; jj < cnt; jj += U) {
