@@ -2,7 +2,9 @@
 skip connection, bf16) fwd + bwd + Adam step on MI355X, with synthetic cached activations.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    (N > 1: one rank per GPU over RCCL.  Launched by torch.distributed.run, every rank reads RANK / LOCAL_RANK /
+     WORLD_SIZE / MASTER_* from the environment; started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) it
+     starts its N ranks itself, as a torch.distributed.run child, BEFORE this process touches the GPU.)
 
 Prints ONE JSON line on rank 0 (contract in the task statement): whole-job tokens/s, plus
 `roofline` for the dominant kernel (HIP events on the launch stream, over the timed region),
@@ -105,6 +107,29 @@ def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.
     return None, None
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run
+    (one rank per GPU, rendezvous on 127.0.0.1) as a CHILD process and return its exit code.  Nothing in this
+    process has initialised the GPU (torch.cuda.device_count() does not), and it never does."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("CLT_BENCH_REHEARSAL"):
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("bench.py: starting", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +157,9 @@ def main():
                          "NOT a measurement of the metric: the line is marked 'simulated')")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,6 +172,11 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        print(f"bench.py: rank {dist.get_rank()} of {dist.get_world_size()} ranks, backend {dist.get_backend()}, "
+              f"device cuda:{local_rank}", file=sys.stderr, flush=True)
+        if args.gpus != world:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used",
+                  file=sys.stderr, flush=True)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -258,7 +291,7 @@ def main():
         step_roofline = {"ms": round(roof_s * 1e3, 3), "frac": round(roof_s / (dt / args.steps), 4),
                          "tokens_per_s_at_roofline": round(tokens_per_step / roof_s, 1)}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and real_world == 1:  # rank 0 at N = 1 only
             sys.path.insert(0, str(ROOT))
             from oracle import cpu_baseline
 

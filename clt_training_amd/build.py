@@ -22,15 +22,19 @@ def _stale(out: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
-    objdir = HERE / "build"
+def build(force: bool = False, verbose: bool = True, tuning: bool = False) -> Path:
+    """tuning=True: -DCLT_TUNING (the kernels' timing / A-B switches read the environment) into libcltmi355_tuning.so,
+    for tools/ only (select it with CLT_LIB=...); the shipped library never reads the environment."""
+    objdir = HERE / ("build_tuning" if tuning else "build")
     objdir.mkdir(exist_ok=True)
+    flags = FLAGS + (["-DCLT_TUNING"] if tuning else [])
+    lib = HERE / "libcltmi355_tuning.so" if tuning else LIB
     headers = [*CSRC.glob("*.h"), HERE.parent / "include" / "clt_mi355.h"]
 
     def compile_one(src):
         obj = objdir / (Path(src).stem + ".o")
         if force or _stale(obj, [CSRC / src, *headers]):
-            cmd = [HIPCC, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+            cmd = [HIPCC, *flags, "-c", str(CSRC / src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -38,13 +42,13 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tuning="--tuning" in sys.argv)

@@ -193,8 +193,7 @@ extern "C" int clt_adam_step(const clt_adam_tensor* tensors, int n_tensors, cons
   CLT_CHECK_ARG(chunk_elems > 0 && chunk_elems % 8 == 0, "clt_adam_step: chunk_elems must be a positive multiple of 8");
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
-  const char* ve = getenv("CLT_ADAM_VARIANT");  // timing experiments: 0 = cached loads/stores, 2 = no unrolling
-  const int var = ve ? atoi(ve) : 1;
+  const int var = tuning_env("CLT_ADAM_VARIANT", 1);  // -DCLT_TUNING builds only: 0 = cached loads/stores, 2 = no unrolling
 #define CLT_ADAM_LAUNCH(VARIANT)                                                                                    \
   hipLaunchKernelGGL(adam_kernel<VARIANT>, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, tensors,    \
                      chunk_tensor, chunk_start, chunk_elems, lr_factor, b1, b2, eps, (float)(1.0 / bc1),            \

@@ -1,5 +1,6 @@
 // Shared helpers for the gfx950 kernels of libcltmi355.so.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -11,6 +12,19 @@
 typedef __bf16 bf16_t;
 
 namespace clt {
+
+// Tuning switches (timing ablations, A/B kernels) are read from the environment ONLY in builds made with -DCLT_TUNING
+// (python -m clt_training_amd.build --tuning -> libcltmi355_tuning.so); the shipped library never reads the environment.
+static inline int tuning_env(const char* name, int dflt) {
+#ifdef CLT_TUNING
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
+
 
 void set_error(const char* fmt, ...);
 

@@ -340,8 +340,7 @@ extern "C" int clt_encoder_gemm_relu(const void* x, const void* W, int in_dtype,
   const int64_t grid_n = ntiles < num_cus() ? ntiles : num_cus();
   dim3 grid((unsigned)grid_n);
   hipStream_t st = (hipStream_t)stream;
-  const char* dbg_env = getenv("CLT_GEMM_DEBUG");  // timing experiments only (skip stores / MFMA / loads)
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  const int dbg = tuning_env("CLT_GEMM_DEBUG", 0);  // -DCLT_TUNING builds only: skip stores / MFMA / loads
   if (gemm_fast_supported(in_dtype, N, M, d) && !(dbg & 16)) {  // 16: force the generic kernel
     FastArgs a = {};
     a.x = (const char*)x;
@@ -394,8 +393,7 @@ extern "C" int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, c
     return CLT_ERR_WORKSPACE;
   }
   if (N == 0) return CLT_OK;
-  const char* dbg_env = getenv("CLT_GEMM_DEBUG");  // 32: never take the fused path
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  const int dbg = tuning_env("CLT_GEMM_DEBUG", 0);  // -DCLT_TUNING builds only; 32: never take the fused path
   if (!(dbg & (16 | 32)) && valid_dtype(in_dtype) && valid_dtype(out_dtype) && aligned16(x) && aligned16(W) &&
       (!bias || (valid_dtype(bias_dtype) && aligned16(bias))) && k >= 1 && k <= M) {
     const FusedPlan pl = fused_plan(in_dtype, out_dtype, N, M, d, k);

@@ -752,7 +752,7 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds
 
 // The LDS-staged kernel serves rows of up to 10 KiB (2 waves * 3 arrays * row <= 64 KiB of LDS) and 8 chunks per lane.
 static inline bool rows_lds_ok(int d, size_t elem, int ch, int narr = 3) {
-  static const bool off = getenv("CLT_ROWS_LDS") && atoi(getenv("CLT_ROWS_LDS")) == 0;  // A/B switch (tests, tuning)
+  static const bool off = tuning_env("CLT_ROWS_LDS", 1) == 0;  // -DCLT_TUNING builds only: A/B against the register kernel
   return !off && ch <= 8 && 2 * (size_t)narr * (size_t)d * elem <= 65536;
 }
 

@@ -29,7 +29,6 @@ under gloo.
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -38,6 +37,22 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 from .config import SparseCoderConfig, TrainConfig
+
+
+@dataclass
+class Routes:
+    """Which of the engine's equivalent kernel routes a step takes.  Everything is on in the product; the A/B tests
+    (fast path == single-pair kernels, fused Adam == grad -> Adam) switch routes off on this object.  Not read from
+    the environment."""
+
+    multi: bool = True       # all live sources of a target in one decode launch (clt_decode_fwd_multi)
+    rows_pass: bool = True   # decoder backward as one row pass per pair (clt_decode_bwd_rows*)
+    fused_adam: bool = True  # Adam applied inside the gradient kernels
+    overlap: bool = True     # tp > 1: encoder half of layer j + 1 on a side stream
+    graph: bool = True       # capture the step in a HIP graph where the trainer supports it
+
+
+ROUTES = Routes()
 
 
 # --------------------------------------------------------------------------- collectives
@@ -417,7 +432,8 @@ class CLTEngine:
         scale = [1.0 if st is me else 1.0 / div for st in self.live]
         Wt = [self.coders[st.layer].W_decs[st.slot] for st in self.live]
         multi = (hasattr(ops, "decode_fwd_multi") and all(w.shape == Wt[0].shape and w.dtype == Wt[0].dtype for w in Wt)
-                 and not os.environ.get("CLT_NO_MULTI"))  # (the switch is for A/B tests and timing only)
+                 and all(st.idx.shape == me.idx.shape and st.v.dtype == me.v.dtype for st in self.live)  # per_layer_k
+                 and ROUTES.multi)
         if multi:  # every live source in ONE launch: fp32 sum over all sources, one rounding, one output write
             srcs = []
             for st, sc_ in zip(self.live, scale):
@@ -485,7 +501,7 @@ class CLTEngine:
         # wrt the activations and the post-encoder sums -- no second gather of decoder rows per token.  Otherwise:
         # the gradient wrt the activations of every live source in one launch, then grad-W rows and segment sums.
         rows_pass = (hasattr(ops, "decode_bwd_rows") and all(w.dtype == G.dtype for w in Wt)
-                     and not os.environ.get("CLT_NO_ROWS_PASS"))  # (the switch is for A/B timing only)
+                     and ROUTES.rows_pass)
         bwd_multi = None
         if not rows_pass and multi and hasattr(ops, "decode_bwd_acts_multi"):  # grad wrt the activations of every live source: ONE launch
             srcs = []

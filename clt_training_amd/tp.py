@@ -5,7 +5,6 @@ construction rule, Adam groups + LR rule, warm-up schedule, step-0 init and step
 (sparsify/__main__.py:173-177)."""
 from __future__ import annotations
 
-import os
 
 from dataclasses import replace
 from typing import Optional
@@ -14,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 from .config import TrainConfig
-from .engine import CLTEngine, Comm, ShardedCoder
+from .engine import ROUTES, CLTEngine, Comm, ShardedCoder
 from .fit_loop import FitLoop
 
 
@@ -66,7 +65,7 @@ class TPTrainer(FitLoop):
         # else consumes them: one micro-step per optimizer step, and an optimizer that has the fused form (Adam).
         # (a unit-norm SAE decoder's gradient projection happens inside the same row pass: engine.layer_step)
         fuse = (cfg.optimizer in ("adam", "adam8") and hasattr(opt, "fused_rows")
-                and cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and not os.environ.get("CLT_NO_FUSED_ADAM"))
+                and cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and ROUTES.fused_adam)
         self.engine.fused_opt = opt if fuse else None
         self.global_step = 0
         self.num_tokens_since_fired = {h: torch.zeros(s.m_local, device=self.device, dtype=torch.long)
@@ -91,7 +90,7 @@ class TPTrainer(FitLoop):
         # the collectives of either half run behind the kernels of the other.  Step 0 (data-dependent init) is serial.
         names = cfg.hookpoints
         overlap = (self.comm.world > 1 and self.device.type == "cuda" and self.global_step > 0
-                   and not os.environ.get("CLT_NO_OVERLAP"))
+                   and ROUTES.overlap)
         pending = {}
         if overlap:
             main = torch.cuda.current_stream(self.device)

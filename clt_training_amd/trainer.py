@@ -9,7 +9,6 @@ step-0 data-dependent init (:547-592), the encode/decode/backward/restore order 
 ``{hookpoint: (inputs[N, d], outputs[N, d])}`` (BASELINE.json north_star)."""
 from __future__ import annotations
 
-import os
 from dataclasses import replace
 from typing import Optional
 
@@ -19,6 +18,7 @@ from torch import Tensor
 from . import fused_state
 from .adam import Adam
 from .config import TrainConfig
+from .engine import ROUTES
 from .fit_loop import FitLoop, WarmupLinearSchedule  # noqa: F401 (re-exported)
 from .runner import CrossLayerRunner
 from .sparse_coder import SparseCoder
@@ -78,7 +78,7 @@ class Trainer(FitLoop):
             [sae.num_latents for sae in self.saes.values()], num_batches)
         # Row gradients of the [M, d] matrices go straight into the Adam update inside the gradient kernels when each
         # optimizer step sees one micro-step (fused_state): no dense .grad, no second pass over the tables.
-        self._fused = (cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and not os.environ.get("CLT_NO_FUSED_ADAM")
+        self._fused = (cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and ROUTES.fused_adam
                        and type(self.optimizers[0]) is Adam
                        # a decoder shared by several targets is read again after its first local backward
                        and not cfg.sae.per_source_tied)

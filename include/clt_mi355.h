@@ -68,9 +68,16 @@ int clt_topk_rows(const void* vals, int val_dtype, int64_t ld, const int64_t* ca
                   int64_t N, int64_t L, int k, void* out_vals, int out_dtype, int64_t* out_idx,
                   clt_stream_t stream);
 
-/* Fused convenience: encoder GEMM + bias + ReLU + row top-k (whole of
- * fused_encoder.py:310-322,372 for activation="topk").  `workspace` holds the
- * pre-activation matrix in out_dtype.  */
+/* Encoder GEMM + bias + ReLU + row top-k in one call (whole of fused_encoder.py:310-322,372 for
+ * activation="topk"); results are those of clt_encoder_gemm_relu -> clt_topk_rows bit for bit.
+ * `workspace`: clt_encode_topk_workspace_bytes(N, M, out_dtype) bytes = room for the pre-activation matrix
+ * [N,M] in out_dtype + a 4 KiB tail that holds a device-side fallback flag.  bf16 operands with
+ * M >= 320 k never form that matrix: the same bytes hold, laid over its front, the sample matrix
+ * [N, M/S], the sample's top-k (values, int64 indices), the per-token thresholds tau[N], and the
+ * candidate lists (8 x u32 per token and 64 latents) with their u8 lengths; the full matrix is written only
+ * by the device-gated fallback launches (a candidate list overflowed or a token failed verification).
+ * Other dtypes / shapes: GEMM into the workspace, then clt_topk_rows over it.  Contents are scratch:
+ * nothing in the workspace needs to survive the call, and calls sharing a workspace must be stream-ordered. */
 size_t clt_encode_topk_workspace_bytes(int64_t N, int64_t M, int out_dtype);
 int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, const void* bias, int bias_dtype,
                         int64_t N, int64_t M, int d, int k, void* out_vals, int out_dtype, int64_t* out_idx,

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from conftest import golden_grad_name, golden_layers, load_golden
+from clt_training_amd.engine import ROUTES
 from oracle import clt_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -265,10 +266,7 @@ def test_trainer_fused_adam_equals_grad_then_adam(monkeypatch):
             batches.append(b)
 
         def run(fused):
-            if fused:
-                monkeypatch.delenv("CLT_NO_FUSED_ADAM", raising=False)
-            else:
-                monkeypatch.setenv("CLT_NO_FUSED_ADAM", "1")
+            monkeypatch.setattr(ROUTES, "fused_adam", fused)
             torch.manual_seed(0)
             cfg = TrainConfig(sae=SparseCoderConfig(dtype="bfloat16", expansion_factor=32, k=k, **kw), hookpoints=list(hooks),
                               cross_layer=cross, optimizer="adam", lr=1e-3, lr_warmup_steps=1, log_to_wandb=False)

@@ -6,6 +6,7 @@ import torch
 
 from oracle import clt_oracle as O
 from oracle import ops_cpu
+from clt_training_amd.engine import ROUTES
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -166,10 +167,7 @@ def test_fused_row_adam_equals_grad_then_adam(monkeypatch):
         batches.append(b)
 
     def run(fused):
-        if fused:
-            monkeypatch.delenv("CLT_NO_FUSED_ADAM", raising=False)
-        else:
-            monkeypatch.setenv("CLT_NO_FUSED_ADAM", "1")
+        monkeypatch.setattr(ROUTES, "fused_adam", fused)
         torch.manual_seed(0)
         cfg = TrainConfig(sae=SparseCoderConfig(dtype="bfloat16", expansion_factor=32, k=k, transcode=True,
                                                 skip_connection=True, post_encoder_scale=True),
@@ -202,7 +200,7 @@ def test_fused_row_adam_equals_grad_then_adam(monkeypatch):
 def test_engine_fast_path_equals_separate_kernels_at_config_widths(monkeypatch, shape):
     """BASELINE configs[2] / configs[3] widths (Llama-3.2-1B CLT: d=2048, k=64; Llama-3-8B SAE: d=4096, k=192, unit-norm
     decoder) through the engine's fast path (one-launch fan-out, row-pass decoder backward, fused Adam where allowed)
-    against the same steps on the single-pair kernels (CLT_NO_MULTI / CLT_NO_ROWS_PASS / CLT_NO_FUSED_ADAM): bf16
+    against the same steps on the single-pair kernels (engine.ROUTES: multi / rows_pass / fused_adam off): bf16
     tolerance of BASELINE.json (the one-launch fan-out rounds the sum over sources once instead of once per source)."""
     from clt_training_amd import SparseCoderConfig, TrainConfig
     from clt_training_amd.tp import TPTrainer
@@ -223,11 +221,8 @@ def test_engine_fast_path_equals_separate_kernels_at_config_widths(monkeypatch, 
         batches.append(b)
 
     def run(fast):
-        for name in ("CLT_NO_MULTI", "CLT_NO_ROWS_PASS", "CLT_NO_FUSED_ADAM"):
-            if fast:
-                monkeypatch.delenv(name, raising=False)
-            else:
-                monkeypatch.setenv(name, "1")
+        for name in ("multi", "rows_pass", "fused_adam"):
+            monkeypatch.setattr(ROUTES, name, fast)
         torch.manual_seed(0)
         cfg = TrainConfig(sae=SparseCoderConfig(dtype="bfloat16", num_latents=M, k=k, **kw), hookpoints=list(hooks),
                           cross_layer=L if kw["transcode"] else 0, optimizer="adam", lr=1e-3, lr_warmup_steps=1,
