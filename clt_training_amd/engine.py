@@ -282,6 +282,8 @@ class CLTEngine:
         self.last_fvu = {}
         self.last_idx = {}
         self.fused_opt = None  # an optimizer with fused_rows() (adam.Adam): see _grad_rows
+        self.keep_outputs = False  # parity tests: keep each target's reconstruction of the local tokens in last_out
+        self.last_out = {}
 
     # ---- helpers
     def _cd(self, lp: ShardedCoder):
@@ -481,6 +483,8 @@ class CLTEngine:
         denorm = (lp.out_norm / d**0.5) if cfg.normalize_io else None  # sparse_coder.py:627-630
         if denorm is not None:
             yhat_r = yhat_r * denorm
+        if self.keep_outputs:
+            self.last_out[j] = yhat_r
 
         # ---------------- FVU on token shards (sparse_coder.py:207-221)
         colsum = comm.all_reduce_(ops.fvu_colsum(y_r, mask_r))
