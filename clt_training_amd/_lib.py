@@ -67,6 +67,7 @@ SIGNATURES = {
     "clt_segment_sum": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "clt_fvu_workspace_bytes": (_sz, [_i64, _i32]),
     "clt_fvu_fwd_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "clt_fvu_fwd_bwd_static": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _i32, _vp]),
     "clt_fvu_colsum": (_i32, [_vp, _i32, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "clt_fvu_partial": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "clt_fvu_grad": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _vp, _f32, _vp, _vp, _i32, _vp]),

@@ -3,6 +3,8 @@
 // Four small launches, all deterministic two-stage reductions (no atomics):
 //   1 column sums of m*y per row block   2 mean[d]   3 per-block (l2, tv)   4 finalize + write G.
 // HBM-bound, algorithmic bytes ~ N*d*(3*sizeof(y) + 2*sizeof(yhat) + sizeof(G)).
+#include <mutex>
+
 #include "common.h"
 
 namespace clt {
@@ -205,22 +207,12 @@ extern "C" size_t clt_fvu_workspace_bytes(int64_t N, int d) {
   return (nb * (size_t)d + nb + (size_t)d + 1 + 2 * nb + 32) * sizeof(float);
 }
 
-extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask,
-                               int64_t N, int d, float gscale, float* out_scalars, void* G, int g_dtype,
-                               void* workspace, size_t workspace_bytes, clt_stream_t stream) {
-  CLT_CHECK_ARG(y && yhat && out_scalars && workspace, "clt_fvu_fwd_bwd: null pointer");
-  CLT_CHECK_ARG(N > 0 && d > 0, "clt_fvu_fwd_bwd: bad sizes");
-  CLT_CHECK_ARG(valid_dtype(y_dtype) && valid_dtype(yhat_dtype) && (!G || valid_dtype(g_dtype)), "clt_fvu_fwd_bwd: bad dtype");
-  CLT_UNSUPPORTED(d % 4 == 0, "clt_fvu_fwd_bwd: d=%d must be a multiple of 4", d);
-  CLT_CHECK_ARG(!G || aligned16(G), "clt_fvu_fwd_bwd: G must be 16-byte aligned");
-  if (workspace_bytes < clt_fvu_workspace_bytes(N, d)) {
-    set_error("clt_fvu_fwd_bwd: workspace too small");
-    return CLT_ERR_WORKSPACE;
-  }
-  hipStream_t st = (hipStream_t)stream;
+// The launches of clt_fvu_fwd_bwd over a float workspace of clt_fvu_workspace_bytes(N, d) bytes (arguments checked).
+static int fvu_fwd_bwd_launch(const char* who, const void* y, int y_dtype, const void* yhat, int yhat_dtype,
+                              const uint8_t* mask, int64_t N, int d, float gscale, float* out_scalars, void* G,
+                              int g_dtype, float* ws, hipStream_t st) {
   const int NB = fvu_blocks(N);
   const int64_t rpb = (N + NB - 1) / NB;
-  float* ws = reinterpret_cast<float*>(workspace);
   float* pcol = ws;
   float* pcnt = pcol + (size_t)NB * d;
   float* mean = pcnt + (NB + 3) / 4 * 4;  // float4 loads of the column sums: keep 16-byte alignment
@@ -239,8 +231,87 @@ extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int
   else
     hipLaunchKernelGGL((fvu_grad_kernel<float>), dim3(gb), dim3(256), 0, st, y, y_dtype, yhat, yhat_dtype, mask, N, d,
                        (const float*)psc, NB, gscale, out_scalars, (float*)G);
-  CLT_CHECK_LAUNCH("clt_fvu_fwd_bwd");
+  CLT_CHECK_LAUNCH(who);
   return CLT_OK;
+}
+
+static int fvu_check_args(const char* who, const void* y, int y_dtype, const void* yhat, int yhat_dtype, int64_t N, int d,
+                          const float* out_scalars, const void* G, int g_dtype) {
+  if (!(y && yhat && out_scalars)) { set_error("%s: null pointer", who); return CLT_ERR_BAD_ARG; }
+  if (!(N > 0 && d > 0)) { set_error("%s: bad sizes", who); return CLT_ERR_BAD_ARG; }
+  if (!(valid_dtype(y_dtype) && valid_dtype(yhat_dtype) && (!G || valid_dtype(g_dtype)))) {
+    set_error("%s: bad dtype", who);
+    return CLT_ERR_BAD_ARG;
+  }
+  if (d % 4 != 0) { set_error("%s: d=%d must be a multiple of 4", who, d); return CLT_ERR_UNSUPPORTED; }
+  if (G && !aligned16(G)) { set_error("%s: G must be 16-byte aligned", who); return CLT_ERR_BAD_ARG; }
+  return CLT_OK;
+}
+
+extern "C" int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask,
+                               int64_t N, int d, float gscale, float* out_scalars, void* G, int g_dtype,
+                               void* workspace, size_t workspace_bytes, clt_stream_t stream) {
+  const int rc = fvu_check_args("clt_fvu_fwd_bwd", y, y_dtype, yhat, yhat_dtype, N, d, out_scalars, G, g_dtype);
+  if (rc != CLT_OK) return rc;
+  CLT_CHECK_ARG(workspace, "clt_fvu_fwd_bwd: null pointer");
+  if (workspace_bytes < clt_fvu_workspace_bytes(N, d)) {
+    set_error("clt_fvu_fwd_bwd: workspace too small");
+    return CLT_ERR_WORKSPACE;
+  }
+  return fvu_fwd_bwd_launch("clt_fvu_fwd_bwd", y, y_dtype, yhat, yhat_dtype, mask, N, d, gscale, out_scalars, G, g_dtype,
+                            reinterpret_cast<float*>(workspace), (hipStream_t)stream);
+}
+
+// ---- clt_fvu_fwd_bwd for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid
+//      hipMalloc): the reduction partials live in a file-scope device array instead of a caller workspace.  Each GPU
+//      the library runs on holds its own copy of the array (at its own address) until the process ends.  In host
+//      code the array's NAME is only a stand-in, not a device address: the per-device address comes from
+//      hipGetSymbolAddress, once per device, and only that pointer is handed to the kernels.
+constexpr int FVU_STATIC_MAX_D = 8192;
+constexpr size_t FVU_SCRATCH_BYTES = 16 * 1024 * 1024 + 64 * 1024;  // >= clt_fvu_workspace_bytes(any N, 8192)
+static __device__ __align__(256) unsigned char scratch[FVU_SCRATCH_BYTES];
+
+constexpr int FVU_MAX_DEVICES = 64;
+static void* g_scratch_ptr[FVU_MAX_DEVICES];  // per device; written once under the mutex, read-only afterwards
+static std::mutex g_scratch_mutex;
+
+static int fvu_scratch_for_current_device(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FVU_MAX_DEVICES) {
+    set_error("clt_fvu_fwd_bwd_static: no current HIP device (or device index >= %d)", FVU_MAX_DEVICES);
+    return CLT_ERR_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));  // the address on THIS device
+    if (e != hipSuccess || !ptr) {
+      set_error("clt_fvu_fwd_bwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+      return CLT_ERR_LAUNCH;
+    }
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = reinterpret_cast<float*>(g_scratch_ptr[dev]);
+  return CLT_OK;
+}
+
+extern "C" int clt_fvu_fwd_bwd_static(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask,
+                                      int64_t N, int d, float gscale, float* out_scalars, void* G, int g_dtype,
+                                      clt_stream_t stream) {
+  const char* who = "clt_fvu_fwd_bwd_static";
+  const int rc = fvu_check_args(who, y, y_dtype, yhat, yhat_dtype, N, d, out_scalars, G, g_dtype);
+  if (rc != CLT_OK) return rc;
+  if (d > FVU_STATIC_MAX_D || clt_fvu_workspace_bytes(N, d) > FVU_SCRATCH_BYTES) {
+    set_error("%s: d=%d exceeds the static scratch (d <= %d); use clt_fvu_fwd_bwd with a caller workspace", who, d,
+              FVU_STATIC_MAX_D);
+    return CLT_ERR_UNSUPPORTED;
+  }
+  float* ws = nullptr;
+  const int rs = fvu_scratch_for_current_device(&ws);
+  if (rs != CLT_OK) return rs;
+  // every partial the kernels read is written earlier in the same call: nothing in the scratch has to start at zero
+  return fvu_fwd_bwd_launch(who, y, y_dtype, yhat, yhat_dtype, mask, N, d, gscale, out_scalars, G, g_dtype, ws,
+                            (hipStream_t)stream);
 }
 
 // ---- the same three stages as separate entry points, for token-sharded (multi-GPU) FVU: the caller all-reduces

@@ -424,6 +424,19 @@ def fvu_fwd_bwd(y: Tensor, yhat: Tensor, mask: Optional[Tensor], gscale: float =
     return sc, G
 
 
+def fvu_fwd_bwd_static(y: Tensor, yhat: Tensor, mask: Optional[Tensor], out_scalars: Tensor, G: Optional[Tensor],
+                       gscale: float = 1.0) -> None:
+    """clt_fvu_fwd_bwd_static: the caller passes EVERY buffer (scalars[3] fp32, G [N,d] or None, mask as bool / uint8);
+    nothing is allocated here or in the library (graph capture, serving loops).  d <= 8192."""
+    N, d = y.shape
+    assert y.is_contiguous() and yhat.is_contiguous() and out_scalars.is_contiguous()
+    assert out_scalars.dtype == torch.float32 and out_scalars.numel() >= 3
+    assert mask is None or (mask.is_contiguous() and mask.element_size() == 1)
+    assert G is None or (G.is_contiguous() and G.shape == y.shape)
+    _call("clt_fvu_fwd_bwd_static", _ptr(y), _dt(y), _ptr(yhat), _dt(yhat), _ptr(mask), N, d, float(gscale),
+          _ptr(out_scalars), _ptr(G), _dt(G) if G is not None else 0, _stream(y))
+
+
 def fvu_colsum(y: Tensor, mask: Optional[Tensor]) -> Tensor:
     """Stage 1 of the token-sharded FVU: local [sum_n m*y (d values), sum_n m]."""
     y = _c(y)

@@ -262,6 +262,18 @@ int clt_fvu_fwd_bwd(const void* y, int y_dtype, const void* yhat, int yhat_dtype
                     int d, float gscale, float* out_scalars, void* G, int g_dtype, void* workspace,
                     size_t workspace_bytes, clt_stream_t stream);
 
+/* clt_fvu_fwd_bwd WITHOUT a caller workspace and without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot allocate -- code under HIP graph capture, tight serving / evaluation loops, harnesses that
+ * forbid hipMalloc.  Same arguments, kernels and results (bit for bit) as clt_fvu_fwd_bwd; the reduction partials live
+ * in a device array inside the library (about 16 MiB on every GPU the library runs on, held until the process ends).
+ * Limit: d <= 8192 (any N); beyond it the call fails with CLT_ERR_UNSUPPORTED and clt_last_error() says so.
+ * Calls no hipMalloc / hipFree / allocating library routine.  The first call on each device looks the array's
+ * address up (hipGetSymbolAddress): make that call outside graph capture.  Every call on a GPU shares that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads) race -- serialise them on one stream.  Nothing in
+ * the array has to start at zero (every partial is written before it is read within one call).               */
+int clt_fvu_fwd_bwd_static(const void* y, int y_dtype, const void* yhat, int yhat_dtype, const uint8_t* mask, int64_t N,
+                           int d, float gscale, float* out_scalars, void* G, int g_dtype, clt_stream_t stream);
+
 /* The three stages of the FVU as separate entry points, for TOKEN-SHARDED targets (tensor parallel: each GPU
  * holds its own tokens of y / yhat after the reduce-scatter).  The caller all-reduces (SUM) colsum_count[d+1]
  * after stage 1 and l2tv[2] after stage 2 -- the scalar / [d] all-reduces DTensor generates for
