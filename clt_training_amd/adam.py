@@ -39,6 +39,8 @@ class Adam(torch.optim.Optimizer):
         self._step = sd.pop("clt_step", self._step)
         super().load_state_dict(sd)
         self._tables = {}  # the cached pointer tables name the state tensors that were just replaced
+        for cache in ("_group_of", "_by_ptr"):
+            self.__dict__.pop(cache, None)
 
     def _state(self, p):
         st = self.state[p]

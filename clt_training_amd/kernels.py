@@ -56,4 +56,4 @@ class TritonDecoder(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             values_grad = triton_dense_dense_sparseout_matmul(grad_output, decoder_weight, sparse_indices)
             values_grad = values_grad.to(sparse_values.dtype)
-        return None, values_grad, decoder_grad, None
+        return None, values_grad, decoder_grad  # (three inputs; the reference returns a stray fourth None, kernels.py:656-662)

@@ -12,6 +12,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from . import ckpt
 from .config import TrainConfig
 from .engine import ROUTES, CLTEngine, Comm, ShardedCoder
 from .fit_loop import FitLoop
@@ -167,9 +168,9 @@ class TPTrainer(FitLoop):
     def save(self, path=None, only=None):
         """``{path}/{hookpoint}/sae.safetensors + cfg.json`` in the reference's unsharded format (the latent shards are
         gathered to rank 0), ``lr_scheduler_0.pt``, ``state.pt`` (global_step) and ``rank_{r}_state.pt``
-        (num_tokens_since_fired) as the reference writes them.  The optimizer state stays sharded:
-        ``optimizer_0.rank{r}.pt`` per rank (the reference gathers and flattens it, utils.py:193-277; resuming
-        on a different tp degree is not supported here)."""
+        (num_tokens_since_fired, best_loss) as the reference writes them, and ``optimizer_0.pt``: the shards of every
+        state tensor gathered to rank 0 and flattened exactly as the reference does (utils.py:193-277, 280-360), so the
+        checkpoint resumes on any tp degree, here or in the reference."""
         from pathlib import Path
 
         path = Path(path or self.default_path())
@@ -182,10 +183,11 @@ class TPTrainer(FitLoop):
         for name, sae in self.saes.items():
             if only is None or name in only:
                 sae.save_to_disk(path / name, self.comm)
-        opt = self.optimizers[0]
-        torch.save({"state": opt.state_dict(), "step": getattr(opt, "_step", None)}, path / f"optimizer_0.rank{rank}.pt")
-        torch.save({"num_tokens_since_fired": {h: t.cpu() for h, t in self.num_tokens_since_fired.items()}},
-                   path / f"rank_{rank}_state.pt")
+        flat = self._gathered_optimizer_state()  # collective: every rank takes part, rank 0 gets the dict
+        if rank == 0:
+            torch.save(flat, path / "optimizer_0.pt")
+        torch.save({"num_tokens_since_fired": {h: t.cpu() for h, t in self.num_tokens_since_fired.items()},
+                    "best_loss": self.best_loss}, path / f"rank_{rank}_state.pt")
         if rank == 0:
             torch.save(self.lr_schedulers[0].state_dict(), path / "lr_scheduler_0.pt")
             torch.save({"global_step": self.global_step}, path / "state.pt")
@@ -193,7 +195,7 @@ class TPTrainer(FitLoop):
             dist.barrier(group=self.comm.group)
 
     def load_state(self, path):
-        """Resume from ``save(path)`` on the same tp degree."""
+        """Resume from ``save(path)`` -- or from a checkpoint the reference wrote -- on any tp degree."""
         from pathlib import Path
 
         path = Path(path)
@@ -205,14 +207,92 @@ class TPTrainer(FitLoop):
                     p.copy_(q.to(p.dtype))
                 for (_, b), (_, c) in zip(sae.named_buffers(), loaded.named_buffers()):
                     b.copy_(c)
-        opt = self.optimizers[0]
-        blob = torch.load(path / f"optimizer_0.rank{rank}.pt", map_location=self.device, weights_only=True)
-        opt.load_state_dict(blob["state"])
-        if blob["step"] is not None:
-            opt._step = blob["step"]
+        self._scatter_optimizer_state(torch.load(path / "optimizer_0.pt", map_location="cpu", weights_only=True))
         self.lr_schedulers[0].load_state_dict(torch.load(path / "lr_scheduler_0.pt", weights_only=True))
         self.global_step = torch.load(path / "state.pt", weights_only=True)["global_step"]
         fired = torch.load(path / f"rank_{rank}_state.pt", map_location=self.device, weights_only=True)
         for h, t in fired["num_tokens_since_fired"].items():
             self.num_tokens_since_fired[h].copy_(t)
+        for h, v in (fired.get("best_loss") or {}).items():
+            if h in self.best_loss:
+                self.best_loss[h] = v
         return self
+
+    # The reference gathers the tp shards of every optimizer state tensor to rank 0 and writes ONE flattened
+    # ``optimizer_0.pt`` whose parameter order is ``sae.parameters()`` of the unsharded module (utils.py:193-277,
+    # 280-360; trainer.py:923-937): the file does not depend on the tp degree.  Same here.
+    @staticmethod
+    def _reference_order(sae: ShardedCoder):
+        """[(reference parameter name, this shard's parameter, latent-sharded?)] in the order of the unsharded
+        ``SparseCoder.parameters()`` (the names and their order do not depend on the widths: a tiny skeleton gives them)."""
+        from .sparse_coder import SparseCoder
+
+        skel = SparseCoder(8, replace(sae.cfg, num_latents=8, k=1), "cpu", dtype=torch.float32)
+        lists = dict(W_dec=sae.W_decs, b_dec=sae.b_decs, W_skip=sae.W_skips, post_enc=sae.post_encs,
+                     post_enc_scale=sae.post_enc_scales)
+        out = []
+        for name, _ in skel.named_parameters():
+            if name == "encoder.weight":
+                p, sharded = sae.W_enc, True
+            elif name == "encoder.bias":
+                p, sharded = sae.b_enc, True
+            else:
+                stem, _, slot = name.partition(".")
+                stem = stem[:-1] if slot else stem  # "W_decs.1" -> ("W_dec", 1); "W_dec" -> ("W_dec", 0)
+                p = lists[stem][int(slot) if slot else 0]
+                sharded = stem in ("W_dec", "post_enc", "post_enc_scale")
+            out.append((name, p, sharded))
+        return out
+
+    def _gathered_optimizer_state(self):
+        opt = self.optimizers[0]
+        state, groups, pos = {}, [], 0
+        for sae, g in zip(self.saes.values(), opt.param_groups):
+            ids = []
+            for _, p, sharded in self._reference_order(sae):
+                if not p.requires_grad:
+                    continue
+                st = opt.state.get(p, {})
+                ent = {}
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if key in st:
+                        t = st[key].detach()
+                        ent[key] = (self.comm.all_gather_rows(t) if sharded else t).cpu()
+                if ent:
+                    if "step" in st:  # (torch.optim.Adam in the CPU tests keeps one per parameter)
+                        ent["step"] = st["step"].detach().cpu()
+                    state[pos] = ent
+                ids.append(pos)
+                pos += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        if self.comm.rank != 0:
+            return None
+        return ckpt.to_reference_layout({"state": state, "param_groups": groups}, getattr(opt, "_step", 0))
+
+    def _scatter_optimizer_state(self, blob):
+        nested, step = ckpt.from_file_layout(blob)
+        opt = self.optimizers[0]
+        pos = 0
+        for sae, g, saved in zip(self.saes.values(), opt.param_groups, nested["param_groups"]):
+            for _, p, sharded in self._reference_order(sae):
+                if not p.requires_grad:
+                    continue
+                st = nested["state"].get(pos)
+                pos += 1
+                if st is None:
+                    continue
+                mine = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()
+                        if k not in ("exp_avg", "exp_avg_sq")}  # (torch.optim.Adam's per-parameter step)
+                for key in ("exp_avg", "exp_avg_sq"):
+                    t = st[key]
+                    if sharded:
+                        t = t[sae.lat_begin:sae.lat_begin + sae.m_local]
+                    assert t.shape == p.shape, (key, tuple(t.shape), tuple(p.shape))
+                    mine[key] = t.to(device=p.device, dtype=p.dtype).contiguous().clone()
+                opt.state[p] = mine
+            for key in ("lr", "initial_lr"):
+                if key in saved:
+                    g[key] = saved[key]
+        if step is not None:
+            opt._step = step
+        opt._tables = {}

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-from . import fused_state
+from . import ckpt, fused_state
 from .adam import Adam
 from .config import TrainConfig
 from .engine import ROUTES
@@ -173,8 +173,10 @@ class Trainer(FitLoop):
 
     # ------------------------------------------------------------------ checkpoint (trainer.py:910-970, 275-354)
     def save(self, path=None, only=None):
-        """``{path}/{hookpoint}/sae.safetensors + cfg.json``, ``optimizer_0.pt``, ``lr_scheduler_0.pt``, ``state.pt``,
-        ``config.json`` and ``rank_0_state.pt`` as the reference lays them out."""
+        """``{path}/{hookpoint}/sae.safetensors + cfg.json``, ``optimizer_0.pt`` (flattened tuple keys, utils.py:193-277),
+        ``lr_scheduler_0.pt``, ``state.pt``, ``config.json`` and ``rank_0_state.pt`` as the reference lays them out: a run
+        saved here resumes in the reference and a run saved by the reference resumes here (tests/test_trainer_golden.py
+        loads a checkpoint the reference wrote)."""
         from pathlib import Path
 
         path = Path(path or self.default_path())
@@ -182,7 +184,9 @@ class Trainer(FitLoop):
         for name, sae in self.saes.items():
             if only is None or name in only:
                 sae.save_to_disk(f"{path}/{name}")
-        torch.save(self.optimizers[0].state_dict(), path / "optimizer_0.pt")
+        # optimizer_0.pt in the reference's flattened layout (utils.py:193-277; trainer.py:931-937)
+        opt = self.optimizers[0]
+        torch.save(ckpt.to_reference_layout(opt.state_dict(), getattr(opt, "_step", 0)), path / "optimizer_0.pt")
         torch.save(self.lr_schedulers[0].state_dict(), path / "lr_scheduler_0.pt")
         torch.save({"global_step": self.global_step}, path / "state.pt")
         self.save_config(path)
@@ -203,7 +207,10 @@ class Trainer(FitLoop):
             if h in self.best_loss:
                 self.best_loss[h] = v
         self.lr_schedulers[0].load_state_dict(torch.load(path / "lr_scheduler_0.pt", weights_only=True))
-        self.optimizers[0].load_state_dict(torch.load(path / "optimizer_0.pt", map_location=self.device, weights_only=True))
+        nested, step = ckpt.from_file_layout(torch.load(path / "optimizer_0.pt", map_location=self.device, weights_only=True))
+        self.optimizers[0].load_state_dict(nested)  # (written by the reference or by save(): the same layout)
+        if step is not None:
+            self.optimizers[0]._step = step
         for name, sae in self.saes.items():
             if (path / name).exists():
                 sae.load_state(f"{path}/{name}")

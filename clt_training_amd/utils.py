@@ -69,4 +69,5 @@ def hip_decode(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor) -> Tensor:
 # The reference selects eager / Triton by environment (utils.py:549-563); here there is one
 # implementation and it fails loudly without the HIP library.
 triton_decode = hip_decode
+eager_decode = hip_decode  # (utils.py:442-445 is the reference's CPU / fallback route; there is no CPU route here)
 decoder_impl = hip_decode

@@ -26,8 +26,8 @@ def load_golden(name):
     return t, meta
 
 
-def golden_layers(t, meta, L=None):
-    """Build oracle LayerParams from a single_* / clt_* golden."""
+def golden_layers(t, meta, L=None, prefix="p"):
+    """Build oracle LayerParams from a single_* / clt_* golden (``prefix``: which parameter snapshot, e.g. "p0")."""
     import torch
 
     from oracle.clt_oracle import LayerParams
@@ -36,7 +36,7 @@ def golden_layers(t, meta, L=None):
     single = L is None
     layers = []
     for l in range(1 if single else L):
-        pre = "p." if single else f"p.{l}."
+        pre = f"{prefix}." if single else f"{prefix}.{l}."
         P = {k[len(pre):]: v for k, v in t.items() if k.startswith(pre)}
 
         def lst(stem, plural):

@@ -47,6 +47,10 @@ def install_harness():
             names = {f.name for f in dataclasses.fields(cls)}
             return cls(**{k: v for k, v in d.items() if k in names})
 
+        def save_json(self, path):  # (trainer.py:949 writes config.json with it)
+            with open(path, "w") as f:
+                json.dump(self.to_dict(), f)
+
     def list_field(*a, **k):
         return dataclasses.field(default_factory=lambda: list(a))
 
@@ -267,7 +271,136 @@ def golden_clt(name, cfg_kw, L, cross, N, d, seed):
                        ref="runner.py:25-201; trainer.py:117-146,598-682"))
 
 
+# ---------------------------------------------------------------- the reference Trainer itself
+def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3, warmup=2):
+    """Drive the reference ``Trainer.fit`` (trainer.py:61-254, 376-865; mesh=None, optimizer="adam", FVU loss) on a
+    random-init GPT-2 built from a config (no download) for ``steps`` batches, and record what pins SURVEY.md rows
+    a18-a20, a22: the coders' parameters as constructed, after the data-dependent step-0 init (captured at the first
+    ``optimizer.step``, with that step's gradients), after every optimizer step, the learning rate each step ran with,
+    ``num_tokens_since_fired`` at the end, and the activations the hooks saw (so the counterpart trainers can be fed
+    cached activations).  The checkpoint ``fit`` writes at its end (sae.safetensors + cfg.json per hookpoint,
+    optimizer_0.pt in the flattened layout of utils.py:193-277, lr_scheduler_0.pt, state.pt, rank_0_state.pt) is kept
+    under tests/golden/<name>_ckpt/: reference-written files for the checkpoint-format tests."""
+    import shutil
+    import tempfile
+
+    from datasets import Dataset
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    import sparsify.trainer as ref_tr
+    from sparsify.config import TrainConfig
+
+    ref_tr.ForwardOutput = _RefForwardOutput  # (isinstance check at trainer.py:617)
+    torch.manual_seed(seed)
+    gcfg = GPT2Config(n_layer=L, n_embd=d, n_head=2, vocab_size=96, n_positions=T, bos_token_id=0, eos_token_id=0)
+    model = GPT2LMHeadModel(gcfg).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    ids = torch.randint(1, 96, (B * steps, T), generator=g)
+    ds = Dataset.from_dict({"input_ids": ids.tolist()}).with_format("torch")
+    tmp = tempfile.mkdtemp()
+    cfg = TrainConfig(sae=SparseCoderConfig(**sae_kw), batch_size=B, optimizer="adam", lr=1e-2, lr_warmup_steps=warmup,
+                      b1=b1, hookpoints=["h.*.mlp"], cross_layer=cross, remove_first_token=True, save_every=10**9,
+                      # filter_bos=True skips `bos_mask &= 0` (trainer.py:687-688), which torch 2.10 rejects (Long into
+                      # Bool); no token id equals bos_token_id here, so the mask is the same: first tokens only
+                      filter_bos=True,
+                      log_to_wandb=False, save_dir=tmp, run_name="run", dead_feature_threshold=B * T)
+    tr = ref_tr.Trainer(cfg, ds, model)
+    hooks = list(tr.saes)
+    t = {}
+    for l, h in enumerate(hooks):
+        for n, p in tr.saes[h].state_dict().items():
+            t[f"p0.{l}.{n}"] = p.detach().clone()
+    # record the activations the hooks consume (transcoder: module input -> module output)
+    acts = []
+
+    def rec(l):
+        def f(module, inputs, outputs):
+            x = inputs[0] if isinstance(inputs, tuple) else inputs
+            y = outputs[0] if isinstance(outputs, tuple) else outputs
+            acts[-1][l] = (x.detach().flatten(0, 1).clone(), y.detach().flatten(0, 1).clone())
+        return f
+
+    handles = [model.base_model.get_submodule(h).register_forward_hook(rec(l)) for l, h in enumerate(hooks)]
+    orig_forward = model.forward
+
+    def forward(*a, **k):
+        acts.append({})
+        return orig_forward(*a, **k)
+
+    model.forward = forward
+    opt = tr.optimizers[0]
+    orig_step = opt.step
+    n_step = [0]
+
+    def step(*a, **k):
+        s = n_step[0]
+        for l, h in enumerate(hooks):
+            if s == 0:
+                for n, p in tr.saes[h].state_dict().items():
+                    t[f"init.{l}.{n}"] = p.detach().clone()
+            for n, p in tr.saes[h].named_parameters():
+                t[f"grad{s}.{l}.{n}"] = p.grad.detach().clone()
+        t[f"lr{s}"] = torch.tensor([float(pg["lr"]) for pg in opt.param_groups])
+        out = orig_step(*a, **k)
+        for l, h in enumerate(hooks):
+            for n, p in tr.saes[h].state_dict().items():
+                t[f"after{s}.{l}.{n}"] = p.detach().clone()
+        n_step[0] += 1
+        return out
+
+    opt.step = step
+    ckpt_note = "written by Trainer.fit's final save (trainer.py:861, 910-964)"
+    try:
+        tr.fit()
+    except RuntimeError as e:
+        # With the safetensors of this image the reference's own save_to_disk refuses a CLT's state dict (W_dec and
+        # W_decs.0 are one tensor under two names; the pinned older safetensors wrote it).  Training is complete by
+        # then; write what the rest of _checkpoint would have (trainer.py:923-962) with the reference's own functions.
+        if n_step[0] != steps or "share memory" not in str(e):
+            raise
+        from sparsify.utils import save_sharded
+
+        path = f"{tmp}/run"
+        os.makedirs(path, exist_ok=True)
+        save_sharded(opt.state_dict(), f"{path}/optimizer_0.pt", None, save_st=False, unflatten=True)
+        torch.save(tr.lr_schedulers[0].state_dict(), f"{path}/lr_scheduler_0.pt")
+        torch.save({"global_step": tr.global_step}, f"{path}/state.pt")
+        torch.save({"num_tokens_since_fired": tr.num_tokens_since_fired, "best_loss": tr.best_loss},
+                   f"{path}/rank_0_state.pt")
+        ckpt_note = ("sae.safetensors NOT written: the reference's save_to_disk raised under this image's safetensors "
+                     "(shared tensors W_dec / W_decs.0); optimizer_0.pt, lr_scheduler_0.pt, state.pt, rank_0_state.pt "
+                     "written with the reference's own save_sharded / torch.save calls of trainer.py:923-962")
+    for hd in handles:
+        hd.remove()
+    assert n_step[0] == steps
+    fit_acts = [a for a in acts if len(a) == L][-steps:]  # (resolve_widths ran the model once on dummy inputs)
+    for s, a in enumerate(fit_acts):
+        for l in range(L):
+            t[f"x{s}.{l}"], t[f"y{s}.{l}"] = a[l]
+    for l, h in enumerate(hooks):
+        t[f"since_fired.{l}"] = tr.num_tokens_since_fired[h].clone()
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[:, 0] = False  # remove_first_token (trainer.py:689-690, 609)
+    t["mask"] = mask.flatten()
+    save(name, t, dict(cfg=sae_kw, L=L, d=d, cross_layer=cross, b1=b1, lr=1e-2, warmup=warmup, steps=steps,
+                       tokens_per_step=B * T, hooks=hooks, seed=seed, num_batches=steps,
+                       dead_feature_threshold=B * T, checkpoint=ckpt_note,
+                       ref="trainer.py:61-254, 376-865 (fit, mesh=None)"))
+    dst = OUT / f"{name}_ckpt"
+    if dst.exists():
+        shutil.rmtree(dst)
+    shutil.copytree(f"{tmp}/run", dst)
+    shutil.rmtree(tmp)
+    print("kept the reference-written checkpoint:", sorted(str(q.relative_to(dst)) for q in dst.rglob("*") if q.is_file()))
+
+
 def main(only=None):
+    if only == "trainer":
+        clt = dict(expansion_factor=8, k=4, transcode=True, skip_connection=True, post_encoder_scale=True)
+        golden_trainer("trainer_clt_b1_09", clt, cross=2, b1=0.9, seed=21)
+        golden_trainer("trainer_clt_b1_00", dict(clt, normalize_io=True), cross=3, b1=0.0, seed=22)
+        golden_trainer("trainer_sae_b1_09", dict(expansion_factor=8, k=4, transcode=False), cross=0, b1=0.9, seed=23)
+        return
     if only == "groupmax":  # added later: leaves the earlier fixtures untouched
         golden_encoder("encoder_groupmax", N=24, d=48, M=512, k=8, seed=12, activation="groupmax")
         golden_single("single_transcoder_groupmax",
