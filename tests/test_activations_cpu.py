@@ -129,7 +129,7 @@ def test_model_driven_fit_equals_cached_activations(tmp_path):
     assert seen_k == [8, 7, 6]
     assert [s for s, _ in logged] == [1, 2, 3]                                           # divmod(global_step + 1, ...), :791
     assert set(logged[0][1]) == {"k"} | {f"{p}/h.{i}.mlp" for p in ("fvu", "dead_pct") for i in range(3)}  # :829-851
-    for f in ("h.0.mlp/sae.safetensors", "h.0.mlp/cfg.json", "optimizer_0.rank0.pt", "lr_scheduler_0.pt", "state.pt",
+    for f in ("h.0.mlp/sae.safetensors", "h.0.mlp/cfg.json", "optimizer_0.pt", "lr_scheduler_0.pt", "state.pt",
               "rank_0_state.pt", "config.json"):
         assert (tmp_path / "driven" / f).exists(), f
     assert json.loads((tmp_path / "driven" / "config.json").read_text())["hookpoints"] == cfg.hookpoints
