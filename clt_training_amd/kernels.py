@@ -29,8 +29,9 @@ def triton_sparse_dense_matmul(sparse_indices: Tensor, sparse_values: Tensor, de
 def triton_dense_dense_sparseout_matmul(dense1: Tensor, dense2: Tensor, at_indices: Tensor) -> Tensor:
     """(dense1 @ dense2).gather(1, at_indices) (kernels.py:332-383); dense2 is [B, N] with
     stride(0) == 1, i.e. the transpose of a row-major [N, B] table."""
-    assert dense1.stride(1) == 1 and dense2.stride(0) == 1
-    table = dense2.t()  # [N, B] contiguous
+    assert dense1.stride(1) == 1
+    table = dense2.t()  # [N, B]: row-major when dense2 is the W_dec.T view the reference passes (stride(0) == 1, its
+    table = table if table.is_contiguous() else table.contiguous()  # own precondition, kernels.py:345-346)
     dummy = torch.ones(at_indices.shape, dtype=torch.float32, device=dense1.device)
     ga, _, _ = ops.decode_bwd_acts(at_indices, dummy, table, dense1.contiguous())
     return ga.to(dense1.dtype)

@@ -47,13 +47,16 @@ def test_triton_decoder_autograd(name):
 
     t, meta = load_golden(name)
     W, acts, idx, G = dev(t, "W", "acts", "idx", "G")
-    Wt = W.T.contiguous().requires_grad_()  # the reference passes W_dec.T (kernels.py:628-640)
-    a = acts.clone().requires_grad_()
-    y = TritonDecoder.apply(idx, a, Wt)
-    torch.testing.assert_close(y.detach().cpu(), t["y"], **FP32)
-    y.backward(G)  # three inputs, three gradients
-    torch.testing.assert_close(Wt.grad.T.cpu(), t["gW"], **FP32)
-    torch.testing.assert_close(a.grad.cpu(), t["gacts"], **FP32)
+    for as_view in (True, False):
+        Wl = W.clone().requires_grad_()
+        a = acts.clone().requires_grad_()
+        # the reference passes the W_dec.T VIEW ([d, M], stride(0) == 1; kernels.py:628-640); a materialised [d, M] works too
+        Wt = Wl.T if as_view else Wl.T.contiguous()
+        y = TritonDecoder.apply(idx, a, Wt)
+        torch.testing.assert_close(y.detach().cpu(), t["y"], **FP32)
+        y.backward(G)  # three inputs, three gradients
+        torch.testing.assert_close(Wl.grad.cpu(), t["gW"], **FP32)
+        torch.testing.assert_close(a.grad.cpu(), t["gacts"], **FP32)
 
 
 @pytest.mark.parametrize("name", NAMES)
