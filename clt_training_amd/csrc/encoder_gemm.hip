@@ -375,10 +375,10 @@ extern "C" int clt_encoder_gemm_relu(const void* x, const void* W, int in_dtype,
 }
 
 // Workspace: the pre-activation matrix of the plain path (which is also the fused path's fallback), with the
-// fused path's smaller buffers laid over its front, and a 4 KiB tail that holds the fallback flag.
+// fused path's smaller buffers laid over its front, and a tail that holds the fallback flags (gemm_fast.h).
 extern "C" size_t clt_encode_topk_workspace_bytes(int64_t N, int64_t M, int out_dtype) {
   if (N <= 0 || M <= 0) return 4096 + 256;
-  return align_up((size_t)N * (size_t)M * dtype_size(out_dtype), 256) + 4096;
+  return align_up((size_t)N * (size_t)M * dtype_size(out_dtype), 256) + fused_flag_bytes(N);
 }
 
 extern "C" int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, const void* bias, int bias_dtype,
@@ -397,10 +397,11 @@ extern "C" int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, c
   if (!(dbg & (16 | 32)) && valid_dtype(in_dtype) && valid_dtype(out_dtype) && aligned16(x) && aligned16(W) &&
       (!bias || (valid_dtype(bias_dtype) && aligned16(bias))) && k >= 1 && k <= M) {
     const FusedPlan pl = fused_plan(in_dtype, out_dtype, N, M, d, k);
-    if (pl.ok && pl.bytes <= need - 4096) {
+    const size_t tail = fused_flag_bytes(N);
+    if (pl.ok && pl.bytes <= need - tail) {
       char* ws = (char*)workspace;
       return launch_fused_encode_topk(pl, x, W, bias, bias_dtype, N, M, d, k, out_vals, out_idx, ws,
-                                      (int*)(ws + need - 4096), num_cus(), dbg, (hipStream_t)stream);
+                                      (int*)(ws + need - tail), num_cus(), dbg, (hipStream_t)stream);
     }
   }
   int rc = clt_encoder_gemm_relu(x, W, in_dtype, bias, bias_dtype, workspace, out_dtype, N, M, d, stream);

@@ -30,6 +30,7 @@ __device__ uint4 g_zero16[1];  // 16 zero bytes: source for absent bias chunks
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int ROWB = 64;                    // bytes of K per row per k-step (32 bf16)
@@ -39,7 +40,7 @@ constexpr int AUX_OFF = 2 * OP_BYTES;     // per stage and wave 1 KiB: [0, 256) 
 constexpr int STAGE_BYTES = 2 * OP_BYTES + 4096;
 constexpr int NTHREADS = 256;
 constexpr int NDMA = 9;                     // LDS-DMAs per wave per stage: 4 W pieces, 4 x pieces, 1 bias/tau piece
-constexpr int QCAP = 512;                    // filter mode: hit-queue entries per wave (4 KiB)
+constexpr int QLANE = 16;                   // filter mode: hit-queue entries per LANE and tile (4 KiB per wave)
 constexpr int NSTORE = 64;                  // store instructions per wave in the epilogue of an interior tile
 
 #define CLT_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -97,12 +98,18 @@ __host__ __device__ __forceinline__ int lt_actual(int v, int mode, int S) {
 // MODE 0: store relu(pre) (OT = bf16 or f32).  MODE 1: per-token threshold filter, no pre matrix (see FastArgs).
 template <typename OT, int MODE>
 __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE_BYTES + (MODE == 1 ? 4 * QCAP * 8 : 0)];
-  if (p.gate && *p.gate == 0) return;  // fallback launch: runs only if the fused path raised its flag
+  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE_BYTES + (MODE == 1 ? 4 * QLANE * 64 * 4 : 0)];
+  int ntt = p.ntt;
+  if (p.gate) {  // fallback launch: runs only if the fused path raised a flag
+    const int flagged = *p.gate;
+    if (flagged == 0) return;
+    if (p.tt_map) ntt = flagged;  // only the flagged token tiles: virtual token tile i is tile tt_map[i]
+  }
   const char* __restrict__ xb = p.x;
   const char* __restrict__ Wb = p.W;
   const char* __restrict__ bias = p.bias;
-  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt, ntt = p.ntt, dbg = p.dbg;
+  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt, dbg = p.dbg;
+  const int* __restrict__ tt_map = p.tt_map;
   const int64_t N = p.N, M = p.M;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
     const int pt = left < GEMM_PANEL ? left : GEMM_PANEL;
     lt = uni(rem / pt);
     tt = uni(pp * GEMM_PANEL + rem % pt);
+    if (tt_map) tt = uni(tt_map[tt]);
   };
 
   // ---- loader state: runs three stages ahead of the multiplier, possibly in the next tile.  Past the last
@@ -324,35 +332,32 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
         }
       } else {
         // ---- filter epilogue: an accumulator that reaches its token's threshold (the lower edge of the bf16
-        //      rounding interval of the k-th best of the sample tiles, from pass A) is appended, as
+        //      rounding interval of the m-th best of the sample tiles, from pass A) is appended, as
         //      (bf16 bits << 16 | position in the list's 64 latents), to the private list of this (token, latent
         //      tile, latent half, lane half); the list's length goes to counts.  No atomics, no pre matrix.
+        //      Scan: per group of 4 accumulators of one token, 4 reads + max-of-4 + ONE compare + one wave-uniform
+        //      branch (8 instructions; ~half of the groups have no hit in any lane).  A group with a hit runs a short
+        //      INLINE body -- per element an EXEC-masked 4-byte write to a lane-private LDS queue -- so a hit costs
+        //      ~30 instructions that sit next to the scan in the instruction stream; the conversion of queue entries
+        //      into list entries is ONE rolled loop at the end of the tile.  (The first version jumped to 64 unrolled
+        //      out-of-line handlers, ~100 KB of code: every hit group paid an instruction-cache miss, ~300 cycles.)
         const int list = (cur_lt * 2 + wm) * 2 + h;
         float tl[4];
-        int cnt[4];
-        uint32_t lbase[4];  // first entry of the (token, list) list, in entries (host checks that it fits 32 bits)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t tok = tok0 + wn * 128 + j * 32 + r32;
           const float t = *reinterpret_cast<const float*>(cb + AUX_OFF + wave * 1024 + 512 + (j * 32 + r32) * 4);
           tl[j] = tok < N ? t : __builtin_inff();
-          cnt[j] = 0;
-          lbase[j] = (uint32_t)((tok * p.nL + list) * FUSED_SLOTS);
         }
-        // Hits go to this wave's LDS queue as (entry index in lists, entry) and leave in whole-wave stores once per
-        // tile: the scan issues no global store, so the counted vmcnt waits of the next k-steps never wait on one.
-        uint2* q = reinterpret_cast<uint2*>(lds + NSTAGE * STAGE_BYTES) + wave * QCAP;
-        int qn = 0;  // wave-uniform
-        auto flush = [&]() {
-          for (int e0 = 0; e0 < qn; e0 += 64) {
-            const int e = e0 + lane;
-            if (e < qn) {
-              const uint2 ent = q[e];
-              if (ent.x != 0xffffffffu && !(dbg & 1)) p.lists[ent.x] = ent.y;
-            }
-          }
-          qn = 0;
-        };
+        // first entry of the (token j = 0, list) list, in entries; token j adds j * lstride (host checks 32 bits)
+        const uint32_t lbase0 = (uint32_t)(((tok0 + wn * 128 + r32) * p.nL + list) * FUSED_SLOTS);
+        const uint32_t lstride = 32u * (uint32_t)p.nL * FUSED_SLOTS;
+        uint32_t* q = reinterpret_cast<uint32_t*>(lds + NSTAGE * STAGE_BYTES) + wave * (QLANE * 64);
+        // byte cursor into this lane's queue: entry e of lane l sits at q[e * 64 + l]; a full queue keeps overwriting
+        // its last slot while the cursor runs on and reports the overflow
+        char* const qb = reinterpret_cast<char*>(q) + lane * 4;
+        uint32_t qoff = 0;  // bytes: 256 per entry
+        constexpr uint32_t QLAST = (QLANE - 1) * 256;
         if (!(dbg & 2))
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -361,39 +366,51 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
             if (i * 32 + 8 * g < lat_left) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                // four independent read + compare pairs, one branch: no compare -> branch latency per element
                 float a[4];
-                unsigned long long m[4];
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) a[qq] = acc_read(acc[i][j][4 * g + qq]);
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) m[qq] = __ballot(a[qq] >= tl[j]);
-                if (__builtin_expect((m[0] | m[1] | m[2] | m[3]) != 0ull, 0)) {  // out of line: no-hit falls through
+                // thresholds are positive, so a >= t  <=>  bits(a) >= bits(t) as SIGNED integers (a negative float is a
+                // negative integer); integer max needs no NaN canonicalisation: v_max3_i32 + v_max_i32 + one compare
+                const int mx = max(max(__float_as_int(a[0]), __float_as_int(a[1])),
+                                   max(__float_as_int(a[2]), __float_as_int(a[3])));
+                if (__ballot(mx >= __float_as_int(tl[j])) != 0ull) {
 #pragma unroll
                   for (int qq = 0; qq < 4; ++qq) {
-                    if (m[qq] != 0ull) {
-                      if (a[qq] >= tl[j]) {
-                        const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m[qq] >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m[qq], 0));
-                        q[pos] = make_uint2(cnt[j] < FUSED_SLOTS ? lbase[j] + cnt[j] : 0xffffffffu,
-                                            (f32_to_bf16_bits(a[qq]) << 16) | (uint32_t)(i * 16 + g * 4 + qq));
-                        ++cnt[j];
-                      }
-                      qn += __popcll(m[qq]);
-                    }
+                    // Straight-line, no EXEC change and no branch per element: EVERY lane writes its entry at its
+                    // cursor, only lanes with a hit advance the cursor (a miss is overwritten by the next write).
+                    // entry = bf16(a) << 16 | 0x3f00 | code: the low half is the bf16 of a constant float whose bf16
+                    // bits are 0x3f00 | code (a normal number in [0.5, 2): exact), so one packed convert builds it.
+                    const uint32_t code = (uint32_t)(j * 64 + i * 16 + g * 4 + qq);
+                    const bf16x2_t pk = {(__bf16)__uint_as_float((0x3f00u | code) << 16), (__bf16)a[qq]};
+                    *reinterpret_cast<uint32_t*>(qb + (qoff < QLAST ? qoff : QLAST)) = __builtin_bit_cast(uint32_t, pk);
+                    qoff += a[qq] >= tl[j] ? 256u : 0u;
                   }
-                  if (qn > QCAP - 4 * 64) flush();  // keep room for the next 4 element-instructions (rare)
                 }
               }
             }
             CLT_FENCE();
           }
         }
-        flush();
+        // ---- queue -> lists (rolled: one copy of this code per kernel)
+        int nq = (int)(qoff >> 8);
+        const bool q_over = nq > QLANE - 1;  // (slot QLANE - 1 is where writes go once the queue is full: not an entry)
+        nq = q_over ? QLANE - 1 : nq;
+        uint32_t cntp = 0;  // the four list lengths of this lane, one byte each
+#pragma unroll 1
+        for (int e = 0; __ballot(e < nq) != 0ull; ++e) {
+          if (e < nq) {
+            const uint32_t ent = q[e * 64 + lane];
+            const uint32_t j = (ent >> 6) & 3u, sh = j * 8u;  // (bits 8..15 hold the 0x3f of the packed convert)
+            const uint32_t c = (cntp >> sh) & 255u;
+            if (c < (uint32_t)FUSED_SLOTS && !(dbg & 1)) p.lists[lbase0 + j * lstride + c] = (ent & 0xffff0000u) | (ent & 63u);
+            cntp += 1u << sh;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t tok = tok0 + wn * 128 + j * 32 + r32;
-          if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(cnt[j] < 255 ? cnt[j] : 255);
+          const uint32_t c = (cntp >> (8 * j)) & 255u;  // > FUSED_SLOTS: the merge kernel reports the overflow
+          if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(q_over ? 255u : c);
         }
       }
       ks = 0;
@@ -481,10 +498,25 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
   ws.flush();
   const float thr_m = bf16_bits_to_f32(svals[tok * k + m - 1]);
   if (__ballot(over) != 0ull || ws.thr_val < thr_m) {
-    if (lane == 0) atomicOr(flag, 1);
+    if (lane == 0) atomicOr(flag + 1 + tok / GEMM_TN, 1);  // this token's 256-token tile goes through the fallback
   }
   ws.finalize();
   write_out<S, R>(ws, out_vals, CLT_BF16, tok, out_idx, k);
+}
+
+// flags[1 .. ntt] -> flags[0] = number of flagged token tiles, flags[1 + ntt ..] = their ids in ascending order.
+// One wave: ballot + prefix count per 64 tiles (order preserving).
+__global__ void fused_compact_kernel(int* __restrict__ flags, int ntt) {
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int t0 = 0; t0 < ntt; t0 += 64) {
+    const int t = t0 + lane;
+    const bool f = t < ntt && flags[1 + t] != 0;
+    const unsigned long long b = __ballot(f);
+    if (f) flags[1 + ntt + base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = t;
+    base += __popcll(b);
+  }
+  if (lane == 0) flags[0] = base;
 }
 
 }  // namespace
@@ -531,7 +563,10 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   // Threshold rank m <= k: the sample's m-th value admits about m * S candidates per token instead of k * S.  The
   // row then holds fewer than k elements at or above it only if fewer than k - m of them fall outside the sample,
   // which for exchangeable latents is P(Poisson((k - m) / (S - 1)) >= m) (the sample's m-th value sits where the
-  // row's density is m per sample size): take the smallest m that keeps this under 1e-12 per token.
+  // row's density is m per sample size): take the smallest m that keeps this under 1e-6 per token.  A failing token
+  // costs one 256-token tile of plain GEMM + top-k (the per-tile fallback: ~60 us at the C2 shape, and only for that
+  // tile), so one failure per ~10 layer calls of 8192 tokens is far cheaper than the extra candidates of a safer
+  // rank (m = 11 instead of 16 at C2: 176 candidates per token instead of 256).  Results are exact either way.
   pl.m = k;
   for (int m = 1; m <= k; ++m) {
     const double lam = (double)(k - m) / (double)(S - 1);
@@ -542,7 +577,7 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
       const double logp = -lam + m * log(lam) - lgamma((double)m + 1.0);
       tail = exp(logp) / (1.0 - lam / (m + 1.0));
     }
-    if (tail < 1e-12) {
+    if (tail < 1e-6) {
       pl.m = m;
       break;
     }
@@ -579,7 +614,7 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   a.ntt = pl.ntt;
   a.lt_S = pl.S;
   a.dbg = dbg;
-  if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) {
+  if (hipMemsetAsync(flag, 0, (size_t)(1 + pl.ntt) * sizeof(int), st) != hipSuccess) {
     set_error("clt_encode_topk_fwd: hipMemsetAsync failed");
     return CLT_ERR_LAUNCH;
   }
@@ -594,7 +629,7 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   uint16_t* svals = (uint16_t*)(ws + pl.off_svals);
   int64_t* sidx = (int64_t*)(ws + pl.off_sidx);
   rc = topk_rows_gated(ws + pl.off_pre_s, CLT_BF16, pl.lds, nullptr, nullptr, N, pl.Ls, k, svals, CLT_BF16, sidx, nullptr,
-                       st);
+                       0, st);
   if (rc != CLT_OK) return rc;
   float* tau = (float*)(ws + pl.off_tau);
   const int64_t Npad = (int64_t)pl.ntt * GEMM_TN;
@@ -621,16 +656,19 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
     hipLaunchKernelGGL((fused_select_kernel<4, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
                        N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
   CLT_CHECK_LAUNCH("clt_encode_topk_fwd");
-  // gated fallback (a list overflowed): the whole batch the plain way, into the same outputs
+  // gated fallback (a list overflowed / a token failed verification): the flagged 256-token tiles the plain way, into
+  // the same outputs.  The pre rows of those tiles land on the front of the workspace, over the lists (consumed by now).
+  hipLaunchKernelGGL(fused_compact_kernel, dim3(1), dim3(64), 0, st, flag, pl.ntt);
   FastArgs pf = a;
   pf.nlt = (int)((M + GEMM_TM - 1) / GEMM_TM);
   pf.lt_mode = LT_ALL;
   pf.pre = ws;
   pf.ldp = M;
   pf.gate = flag;
+  pf.tt_map = flag + 1 + pl.ntt;
   rc = launch_gemm_fast(pf, CLT_BF16, false, cus, st);
   if (rc != CLT_OK) return rc;
-  return topk_rows_gated(ws, CLT_BF16, M, nullptr, nullptr, N, M, k, out_vals, CLT_BF16, out_idx, flag, st);
+  return topk_rows_gated(ws, CLT_BF16, M, nullptr, nullptr, N, M, k, out_vals, CLT_BF16, out_idx, flag, GEMM_TN, st);
 }
 
 }  // namespace clt

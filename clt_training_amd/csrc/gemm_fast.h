@@ -49,7 +49,8 @@ struct FastArgs {
   uint32_t* lists;
   uint8_t* counts;
   int nL;
-  const int* gate;  // if set, the kernel returns at once unless *gate != 0
+  const int* gate;    // if set, the kernel returns at once unless *gate != 0 ...
+  const int* tt_map;  // ... and, if tt_map is set too, *gate is the number of token tiles to do and tt_map[i] their ids
   int dbg;
 };
 
@@ -62,8 +63,11 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 //           sample and, from its k-th value, a threshold no larger than the k-th value of the whole row;
 //   pass B  GEMM over the other tiles whose epilogue keeps only accumulators that reach the token's threshold;
 //   merge   per token, sample top-k + candidates -> top-k (same key order as clt_topk_rows);
-//   gated fallback: if a candidate list overflowed (flag raised on the device), the plain GEMM + top-k launches
-//           that follow redo the batch; otherwise they return at once.  No host synchronisation anywhere.
+//   gated fallback: a token whose candidate list overflowed or whose merged top-k failed verification raises the flag of
+//           its 256-token tile (device memory); a one-wave launch compacts the flagged tile ids, and the plain GEMM +
+//           top-k launches that follow redo ONLY those token tiles -- or return at once when there is none.  No host
+//           synchronisation anywhere.  Flag area (ints): [0] number of flagged tiles, [1 .. ntt] per-tile flags,
+//           [1 + ntt .. 1 + 2 ntt) the compacted tile ids.
 struct FusedPlan {
   bool ok;
   int S, nltA, nltB, ntt, nL;
@@ -72,6 +76,11 @@ struct FusedPlan {
   size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, bytes;
 };
 FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k);
+// bytes of the flag area at the end of the clt_encode_topk_fwd workspace
+inline size_t fused_flag_bytes(int64_t N) {
+  const int64_t ntt = (N + GEMM_TN - 1) / GEMM_TN;
+  return align_up((size_t)(1 + 2 * (ntt > 0 ? ntt : 0)) * sizeof(int), 4096);
+}
 int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, const void* bias, int bias_dtype,
                              int64_t N, int64_t M, int d, int k, void* out_vals, int64_t* out_idx, char* ws, int* flag,
                              int cus, int dbg, hipStream_t st);

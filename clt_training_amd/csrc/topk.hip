@@ -19,8 +19,11 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const VT* __restrict__ v
                                                         const int64_t* __restrict__ cand_idx,
                                                         const int32_t* __restrict__ counts, int64_t N, int64_t L,
                                                         int k, void* __restrict__ out_vals, int out_dtype,
-                                                        int64_t* __restrict__ out_idx, const int* __restrict__ gate) {
-  if (gate && *gate == 0) return;  // fallback launch of the fused encoder path: runs only if the flag was raised
+                                                        int64_t* __restrict__ out_idx, const int* __restrict__ gate,
+                                                        int gate_rows) {
+  // fallback launch of the fused encoder path: runs only if a flag was raised -- gate[0] = number of flagged token
+  // tiles; with gate_rows > 0 a row runs only if ITS tile of gate_rows rows is flagged (gate[1 + row / gate_rows])
+  if (gate && *gate == 0) return;
   constexpr int C = (R - S) * 64;
   constexpr int EPL = VEC ? (16 / (int)sizeof(VT)) : 1;
   __shared__ u64 lds_q[4][C];
@@ -30,6 +33,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const VT* __restrict__ v
   const int64_t row = WPR == 4 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
   const int part = WPR == 4 ? wave : 0;
   if (WPR == 1 && row >= N) return;
+  if (gate && gate_rows > 0 && gate[1 + row / gate_rows] == 0) return;  // wave-uniform (block-uniform for WPR == 4)
 
   constexpr bool RX = WPR == 1 && S <= 2;  // radix flush for one wave per row; the 4-wave LDS merge keeps sorted lists
   WaveSelect<S, R, RX> ws;
@@ -109,41 +113,41 @@ using namespace clt;
 template <typename VT, int S, int R>
 static void launch_topk(bool long_rows, bool vec, hipStream_t st, const void* vals, int64_t ld, const int64_t* cand_idx,
                         const int32_t* counts, int64_t N, int64_t L, int k, void* out_vals, int out_dtype, int64_t* out_idx,
-                        const int* gate) {
+                        const int* gate, int gate_rows) {
   if (long_rows) {
     dim3 grid((unsigned)N);
     if (vec)
       hipLaunchKernelGGL((topk_rows_kernel<VT, S, R, 4, true>), grid, dim3(256), 0, st, (const VT*)vals, ld, cand_idx,
-                         counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+                         counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
     else
       hipLaunchKernelGGL((topk_rows_kernel<VT, S, R, 4, false>), grid, dim3(256), 0, st, (const VT*)vals, ld,
-                         cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+                         cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
   } else {
     dim3 grid((unsigned)((N + 3) / 4));
     if (vec)
       hipLaunchKernelGGL((topk_rows_kernel<VT, S, R, 1, true>), grid, dim3(256), 0, st, (const VT*)vals, ld, cand_idx,
-                         counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+                         counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
     else
       hipLaunchKernelGGL((topk_rows_kernel<VT, S, R, 1, false>), grid, dim3(256), 0, st, (const VT*)vals, ld,
-                         cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+                         cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
   }
 }
 
 template <typename VT>
 static void launch_topk_s(int S, bool long_rows, bool vec, hipStream_t st, const void* vals, int64_t ld,
                           const int64_t* cand_idx, const int32_t* counts, int64_t N, int64_t L, int k, void* out_vals,
-                          int out_dtype, int64_t* out_idx, const int* gate) {
+                          int out_dtype, int64_t* out_idx, const int* gate, int gate_rows) {
   if (S == 1)
-    launch_topk<VT, 1, 4>(long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+    launch_topk<VT, 1, 4>(long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
   else if (S == 2)
-    launch_topk<VT, 2, 8>(long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+    launch_topk<VT, 2, 8>(long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
   else
-    launch_topk<VT, 4, 8>(long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+    launch_topk<VT, 4, 8>(long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
 }
 
 int clt::topk_rows_gated(const void* vals, int val_dtype, int64_t ld, const int64_t* cand_idx, const int32_t* counts,
                          int64_t N, int64_t L, int k, void* out_vals, int out_dtype, int64_t* out_idx, const int* gate,
-                         hipStream_t stream) {
+                         int gate_rows, hipStream_t stream) {
   CLT_CHECK_ARG(vals && out_vals && out_idx, "clt_topk_rows: null pointer");
   CLT_CHECK_ARG(N >= 0 && L > 0 && ld >= L && L < (1ll << 31), "clt_topk_rows: bad sizes N=%lld L=%lld ld=%lld",
                 (long long)N, (long long)L, (long long)ld);
@@ -159,9 +163,9 @@ int clt::topk_rows_gated(const void* vals, int val_dtype, int64_t ld, const int6
   const bool long_rows = L >= 32768 || (L >= 4096 && N < 4096);
   hipStream_t st = stream;
   if (val_dtype == CLT_BF16)
-    launch_topk_s<bf16_t>(S, long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+    launch_topk_s<bf16_t>(S, long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
   else
-    launch_topk_s<float>(S, long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate);
+    launch_topk_s<float>(S, long_rows, vec, st, vals, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, gate, gate_rows);
   CLT_CHECK_LAUNCH("clt_topk_rows");
   return CLT_OK;
 }
@@ -169,7 +173,7 @@ int clt::topk_rows_gated(const void* vals, int val_dtype, int64_t ld, const int6
 extern "C" int clt_topk_rows(const void* vals, int val_dtype, int64_t ld, const int64_t* cand_idx,
                              const int32_t* counts, int64_t N, int64_t L, int k, void* out_vals, int out_dtype,
                              int64_t* out_idx, clt_stream_t stream) {
-  return topk_rows_gated(vals, val_dtype, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, nullptr,
+  return topk_rows_gated(vals, val_dtype, ld, cand_idx, counts, N, L, k, out_vals, out_dtype, out_idx, nullptr, 0,
                          (hipStream_t)stream);
 }
 

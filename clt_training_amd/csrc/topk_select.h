@@ -261,9 +261,10 @@ __device__ __forceinline__ void write_out(WaveSelect<S, R, RX>& ws, void* out_ba
   }
 }
 
-// clt_topk_rows with a device-side gate: when gate != nullptr the kernel returns at once unless *gate != 0.
+// clt_topk_rows with a device-side gate: when gate != nullptr the kernel returns at once unless gate[0] != 0, and with
+// gate_rows > 0 a row is processed only if gate[1 + row / gate_rows] != 0 (the fused encoder's per-token-tile fallback).
 int topk_rows_gated(const void* vals, int val_dtype, int64_t ld, const int64_t* cand_idx, const int32_t* counts,
                     int64_t N, int64_t L, int k, void* out_vals, int out_dtype, int64_t* out_idx, const int* gate,
-                    hipStream_t stream);
+                    int gate_rows, hipStream_t stream);
 
 }  // namespace clt

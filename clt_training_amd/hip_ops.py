@@ -167,6 +167,20 @@ def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=Non
     return ov, oi
 
 
+def encode_topk_fallback_tiles(x: Tensor, M: int, out_dtype=None):
+    """Diagnostics (tools/, tests; SYNCHRONISES): after an ``encode_topk(x, W[M, d], ...)`` call on this device, how many
+    of its 256-token tiles went through the exact fallback (plain GEMM + row top-k) -> (flagged tiles, all tiles).
+    Reads the flag area at the end of the call's workspace (csrc/gemm_fast.h)."""
+    N = x.shape[0]
+    out_dtype = out_dtype or x.dtype
+    nbytes = _lib.load().clt_encode_topk_workspace_bytes(N, M, _DT[out_dtype])
+    ntt = (N + 255) // 256
+    tail = -(-(4 * (1 + 2 * ntt)) // 4096) * 4096
+    ws = workspace(x.device, nbytes, "pre")
+    flags = ws[nbytes - tail:nbytes - tail + 4 * (1 + ntt)].view(torch.int32)
+    return int(flags[0]), ntt
+
+
 # ----------------------------------------------------------------------------- decoder
 def decode_fwd(idx: Tensor, v: Tensor, W: Tensor, *, post_enc: Optional[Tensor] = None,
                post_scale: Optional[Tensor] = None, bias: Optional[Tensor] = None, out: Optional[Tensor] = None,

@@ -553,6 +553,32 @@ def test_fused_encode_topk_few_positives_and_overflow(ops):
     assert torch.equal(i_ref[pos], torch.arange(k, device=DEV).expand(int(pos.sum()), k))  # lowest-index tie rule
 
 
+def test_fused_encode_topk_fallback_is_per_token_tile(ops):
+    """Only the 256-token tiles that hold a failing token are redone the plain way.  Tokens 300..340 see thousands of
+    exact ties at their threshold (their candidate lists overflow); every other token is ordinary.  The result is that
+    of GEMM + row top-k everywhere, and exactly one of the 5 token tiles is flagged."""
+    g = torch.Generator().manual_seed(9)
+    N, M, d, k = 1200, 32768, 64, 32
+    x = torch.randn(N, d, generator=g)
+    x[300:341] = 0.0  # pre-activation = bias for these tokens
+    x = x.to(torch.bfloat16).to(DEV)
+    W = (torch.randn(M, d, generator=g) / 8).to(torch.bfloat16).to(DEV)
+    b = (0.01 * torch.randn(M, generator=g)).to(DEV)
+    b[::3] = 0.5  # a third of the latents tie for the best value of the zero tokens
+    v_ref, i_ref = _plain_encode_topk(ops, x, W, b, k)
+    v, i = ops.encode_topk(x, W, b, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+    assert torch.equal(i[300, :4].cpu(), torch.tensor([0, 3, 6, 9]))  # lowest-index tie rule through the fallback
+    flagged, tiles = ops.encode_topk_fallback_tiles(x, M)
+    assert (flagged, tiles) == (1, 5)
+    # an ordinary batch flags nothing
+    x2 = torch.randn(N, d, generator=g).to(torch.bfloat16).to(DEV)
+    v, i = ops.encode_topk(x2, W, b, k)
+    v_ref, i_ref = _plain_encode_topk(ops, x2, W, b, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+    assert ops.encode_topk_fallback_tiles(x2, M)[0] == 0
+
+
 # --------------------------------------------------------------------------- FVU
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("masked", [False, True])
