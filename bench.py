@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="rehearse rank 0's compute of a W-rank run on one GPU (collectives are local stand-ins; "
                          "NOT a measurement of the metric: the line is marked 'simulated')")
+    ap.add_argument("--routes-off", default="", help="A/B timing only: comma-separated engine.ROUTES switches to turn off")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -182,6 +183,11 @@ def main():
 
     from clt_training_amd import SparseCoderConfig, TrainConfig, Trainer
     from clt_training_amd import hip_ops
+    from clt_training_amd.engine import ROUTES
+
+    for name in filter(None, args.routes_off.split(",")):
+        assert hasattr(ROUTES, name), name
+        setattr(ROUTES, name, False)
 
     L, d, k = args.layers, args.d_model, args.k
     M = d * args.expansion

