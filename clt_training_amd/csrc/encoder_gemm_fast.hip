@@ -547,8 +547,12 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k) {
   FusedPlan pl = {};
   if (!gemm_fast_supported(in_dtype, N, M, d) || out_dtype != CLT_BF16 || k < 1 || k > 256) return pl;
-  // lists hold FUSED_SLOTS entries per 64 latents: keep the expected 64 * k * S / M entries per list under 0.4
-  int64_t S = M / (160 * (int64_t)k);
+  // Sample stride: pass A (store mode, ~1.7x the cost per tile of the filter mode, plus a row top-k over M / S columns)
+  // wants S large; the candidate lists (FUSED_SLOTS entries per 64 latents) want the expected 64 * m * S / M entries per
+  // list small.  An overflowing list costs only its 256-token tile's fallback (~1/ntt of a plain pass), so lists may run
+  // at ~1 expected entry (P(> 8) ~ 1e-6 per list): S up to M / (40 k).  Latent shards (M / tp rows) therefore still take
+  // the fused path: M = 12288, k = 32 -> S = 9 (was 2); M = 16384, k = 64 -> S = 6 (was unfused).
+  int64_t S = M / (40 * (int64_t)k);
   if (S > 16) S = 16;
   if (S < 2) return pl;
   const int64_t nlt = (M + GEMM_TM - 1) / GEMM_TM, ntt = (N + GEMM_TN - 1) / GEMM_TN;
