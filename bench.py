@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="rehearse rank 0's compute of a W-rank run on one GPU (collectives are local stand-ins; "
                          "NOT a measurement of the metric: the line is marked 'simulated')")
+    ap.add_argument("--coalesce", default="none", choices=["none", "concat"],
+                    help="concat = BASELINE configs[4]: per-target tied decoder (one W_dec per layer), post_encoder_scale; "
+                         "a secondary data point, not the metric")
     ap.add_argument("--routes-off", default="", help="A/B timing only: comma-separated engine.ROUTES switches to turn off")
     args = ap.parse_args()
 
@@ -194,7 +197,8 @@ def main():
     N = args.tokens
     hooks = [f"h.{i}.mlp" for i in range(L)]
     sae_cfg = SparseCoderConfig(dtype=args.dtype if args.dtype == "bfloat16" else "none", expansion_factor=args.expansion,
-                                k=k, transcode=not args.sae, skip_connection=not args.sae, activation=args.activation)
+                                k=k, transcode=not args.sae, skip_connection=not args.sae, activation=args.activation,
+                                coalesce_topk=args.coalesce, post_encoder_scale=args.coalesce == "concat")
     cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=0 if args.sae else L, optimizer=args.optimizer, lr=2e-4,
                       lr_warmup_steps=50, log_to_wandb=False, force_lr_warmup=args.optimizer == "signum")
     act_dtype = torch.bfloat16 if args.dtype == "bfloat16" else torch.float32
@@ -310,7 +314,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": f"GPT-2 small CLT: {L} layers, cross_layer={L}, d={d}, latents={M}, k={k}, "
                                    f"skip_connection, {args.dtype} weights, {'Adam' if args.optimizer == 'adam' else 'SignSGD'}{'' if args.activation == 'topk' else ', ' + args.activation}; {N} tokens/step/GPU "
-                                   f"(BASELINE.json configs[1])",
+                                   f"({'BASELINE.json configs[4]: coalesce_topk=concat, post_encoder_scale' if args.coalesce == 'concat' else 'BASELINE.json configs[1]'})",
                        "tokens_per_step": tokens_per_step, "params_per_gpu": P_total, "parallelism": parallelism},
             "fvu_last": round(float(sum(float(v) for v in fv.values()) / len(fv)), 5),
             "roofline": roofline, "step_roofline": step_roofline, "kernels": kernels, "cpu_baseline": cpu,

@@ -155,16 +155,21 @@ class ShardedCoder(nn.Module):
     def __init__(self, d_in: int, cfg: SparseCoderConfig, device, rank: int = 0, tp: int = 1,
                  dtype: torch.dtype = torch.float32):
         super().__init__()
-        if cfg.coalesce_topk != "none" or cfg.per_source_tied or cfg.secondary_target_tied:
-            raise NotImplementedError("the sharded engine implements coalesce_topk='none'")
+        if (cfg.coalesce_topk not in ("none", "concat") or cfg.topk_coalesced or cfg.per_source_tied
+                or cfg.secondary_target_tied):
+            raise NotImplementedError("the sharded engine implements coalesce_topk='none' and 'concat' "
+                                      "(topk_coalesced=False); the other modes run on the autograd mirror")
         self.cfg, self.d_in, self.rank, self.tp = cfg, d_in, rank, tp
         self.num_latents = cfg.num_latents or d_in * cfg.expansion_factor
         assert self.num_latents % tp == 0, "latents must divide evenly over the tp ranks"
         self.m_local = self.num_latents // tp
         self.lat_begin = rank * self.m_local
-        self.n_slots = max(1, cfg.n_targets if cfg.transcode else 1)
+        self.n_slots = max(1, cfg.n_targets if cfg.transcode else 1)  # targets this layer writes to (liveness)
+        # "concat" (runner.py:93-127, sparse_coder.py:324-338): ONE decoder / bias / skip matrix per layer -- the TARGET
+        # layer's -- and one post-encoder vector pair per target slot of the source
+        self.n_dec = 1 if cfg.coalesce_topk == "concat" else self.n_slots
         wd = cfg.torch_dtype or dtype
-        Ml, T = self.m_local, self.n_slots
+        Ml, T = self.m_local, self.n_dec
         scaling = 1.0 / d_in**0.5  # nn.Linear default init == U(-1/sqrt(d), 1/sqrt(d)) (sparse_coder.py:271-284)
         w = (torch.rand(Ml, d_in, device=device, dtype=torch.float32) * (2.0 * scaling) - scaling).to(wd)
         self.W_enc = nn.Parameter(w)
@@ -182,10 +187,10 @@ class ShardedCoder(nn.Module):
         ) if cfg.skip_connection else None
         self.post_encs = nn.ParameterList(
             [nn.Parameter(torch.zeros(Ml, device=device, dtype=dtype), requires_grad=cfg.train_post_encoder)
-             for _ in range(T)])
+             for _ in range(self.n_slots)])
         self.post_enc_scales = nn.ParameterList(
             [nn.Parameter((torch.ones if i == 0 else torch.zeros)(Ml, device=device, dtype=dtype),
-                          requires_grad=cfg.train_post_encoder) for i in range(T)]
+                          requires_grad=cfg.train_post_encoder) for i in range(self.n_slots)]
         ) if cfg.post_encoder_scale else None
         if cfg.normalize_io:
             self.register_buffer("in_norm", torch.ones(1, device=device, dtype=dtype))
@@ -206,11 +211,12 @@ class ShardedCoder(nn.Module):
         with torch.no_grad():
             sc.W_enc.data = sae.encoder.weight.data[lo:hi].clone().to(device)
             sc.b_enc.data = sae.encoder.bias.data[lo:hi].clone().to(device)
-            for i in range(T):
+            for i in range(sc.n_dec):
                 sc.W_decs[i].data = slot("W_decs", "W_dec", i).data[lo:hi].clone().to(device)
                 sc.b_decs[i].data = slot("b_decs", "b_dec", i).data.clone().to(device)
                 if sc.W_skips is not None:
                     sc.W_skips[i].data = slot("W_skips", "W_skip", i).data.clone().to(device)
+            for i in range(T):
                 sc.post_encs[i].data = slot("post_encs", "post_enc", i).data[lo:hi].clone().to(device)
                 if sc.post_enc_scales is not None:
                     sc.post_enc_scales[i].data = slot("post_enc_scales", "post_enc_scale", i).data[lo:hi].clone().to(device)
@@ -233,11 +239,12 @@ class ShardedCoder(nn.Module):
             return comm.all_gather_rows(t.detach()).cpu()
 
         full = {"encoder.weight": rows(self.W_enc), "encoder.bias": rows(self.b_enc)}
-        for i in range(self.n_slots):
+        for i in range(self.n_dec):
             full[f"W_decs.{i}"] = rows(self.W_decs[i])
             full[f"b_decs.{i}"] = self.b_decs[i].detach().cpu()
             if self.W_skips is not None:
                 full[f"W_skips.{i}"] = self.W_skips[i].detach().cpu()
+        for i in range(self.n_slots):
             full[f"post_encs.{i}"] = rows(self.post_encs[i])
             if self.post_enc_scales is not None:
                 full[f"post_enc_scales.{i}"] = rows(self.post_enc_scales[i])
@@ -325,7 +332,7 @@ class CLTEngine:
         cs = self.coders
         L = len(cs)
         if not (packed and ROUTES.pack and L > 0 and all(c.W_skips is not None and c.d_in == cs[0].d_in for c in cs)
-                and not any(c.cfg.divide_cross_layer for c in cs)):
+                and not any(c.cfg.divide_cross_layer or c.cfg.coalesce_topk != "none" for c in cs)):
             return
         d = cs[0].d_in
         order = [(j, i) for j in range(L) for i in range(L) if 0 <= j - i < cs[i].n_slots]  # live sources ascend
@@ -488,6 +495,12 @@ class CLTEngine:
         N, k = v.shape  # (4 * cfg.k slots per row under batchtopk)
         me = _Live(j, enc["xn_r"], x_enc, v, idx, torch.zeros(N, k, dtype=torch.float32, device=v.device))
         self.live.append(me)
+        if cfg.coalesce_topk == "concat":
+            fvu = self._concat_target(j, me, y_r, mask_r, acc_steps)
+            self._advance(acc_steps)
+            self.last_fvu[j] = fvu
+            self.last_idx[j] = idx
+            return fvu
         div = max(1, len(self.live) - 1) if cfg.divide_cross_layer else 1  # runner.py:46-49
 
         # ---------------- forward: partial decode of every live source into this target
@@ -652,7 +665,97 @@ class CLTEngine:
                     self._acc_grad(ps, gs)
                 self._acc_grad(li.post_encs[t], gp)
 
-        # ---------------- advance; deferred encoder backward (runner.py:56-59,193-197; fused_encoder.py:92-155)
+        self._advance(acc_steps)
+        self.last_fvu[j] = fvu
+        self.last_idx[j] = idx if enc.get("fired") is None else enc["fired"]  # merged global indices (trainer.py:622-628)
+        return fvu
+
+    @torch.no_grad()
+    def _concat_target(self, j: int, me: _Live, y_r: Tensor, mask_r: Optional[Tensor], acc_steps: int) -> Tensor:
+        """``coalesce_topk="concat"`` with ``topk_coalesced=False`` (runner.py:52-55, 93-127; BASELINE configs[4]): the
+        candidates of every live source -- post-encoder affine of the source's slot for this target applied -- form ONE
+        bag of k * n_live entries per token, decoded with the TARGET layer's single ``W_dec``; only the target's
+        ``b_dec`` / ``W_skip`` apply.  Forward: one fan-out launch whose sources all name the same table.  Backward: the
+        concatenated entries get one segment build and ONE row pass over the table (weight gradient -> Adam in the
+        pass, and the gradient wrt every entry); the per-source affine backward is elementwise on [N, k]."""
+        ops, comm = self.ops, self.comm
+        lp = self.coders[j]
+        cfg = lp.cfg
+        cd = self._cd(lp)
+        d = lp.d_in
+        W = lp.W_decs[0]
+        denorm = (lp.out_norm / d**0.5) if cfg.normalize_io else None
+        srcs = []
+        for st in self.live:
+            li = self.coders[st.layer]
+            t = st.slot
+            srcs.append(dict(idx=st.idx, v=st.v, W=W, post_enc=li.post_encs[t],
+                             post_scale=li.post_enc_scales[t] if li.post_enc_scales is not None else None,
+                             lat_begin=lp.lat_begin, weight=1.0))
+        S = _mm_f32(me.xn_r, lp.W_skips[0].to(cd).t()) if lp.W_skips is not None else None  # sparse_coder.py:184-190
+        bias = lp.b_decs[0].float()
+        rb = W.dtype == torch.bfloat16
+        if S is not None and comm.world == 1 and denorm is None:
+            yhat_r, acts_l = ops.decode_fwd_multi(srcs, bias=bias, out=S, accumulate=True, round_acts=rb, want_acts=True)
+        else:
+            P, acts_l = ops.decode_fwd_multi(srcs, round_acts=rb, want_acts=True)
+            yhat_r = comm.reduce_scatter_rows(P).float() + (bias if S is None else S + bias)
+            if denorm is not None:
+                yhat_r = yhat_r * denorm
+        if self.keep_outputs:
+            self.last_out[j] = yhat_r
+        colsum = comm.all_reduce_(ops.fvu_colsum(y_r, mask_r))
+        l2tv = comm.all_reduce_(ops.fvu_partial(y_r, yhat_r, mask_r, colsum))
+        sc, G_r = ops.fvu_grad(y_r, yhat_r, mask_r, l2tv, gscale=1.0 / acc_steps, g_dtype=cd)
+        if denorm is not None:
+            G_r = (G_r.float() * denorm).to(cd)
+        G = comm.all_gather_rows(G_r)
+        self._acc_grad(lp.b_decs[0], G_r.sum(0, dtype=torch.float32))
+        if lp.W_skips is not None:
+            self._acc_grad(lp.W_skips[0], _mm_f32(G_r.mT, me.xn_r))
+        # ---- one bag per token: [N, k * n_live]
+        idx_cat = torch.cat([st.idx for st in self.live], 1)
+        acts_cat = torch.cat(acts_l, 1)
+        v_cat = torch.cat([st.v for st in self.live], 1)
+        seg = ops.segments_build(idx_cat, lp.m_local, lat_begin=lp.lat_begin)
+        ga_cat = torch.zeros(idx_cat.shape, dtype=torch.float32, device=idx_cat.device)  # stays 0 for other shards' entries
+        if W.dtype == G.dtype and ROUTES.rows_pass and hasattr(ops, "decode_bwd_rows"):
+            gW, _, _ = ops.decode_bwd_rows(seg, acts_cat.view(-1), v_cat, W.data, G, ga_cat, adam=self._fused_state(W, acc_steps))
+            if gW is not None:
+                self._acc_grad(W, gW)
+        else:
+            ops.decode_bwd_acts(idx_cat, v_cat, W, G, grad_acts=ga_cat, lat_begin=lp.lat_begin)
+            self._grad_rows(W, seg, acts_cat.view(-1), G, acc_steps)
+        # ---- per source: backward of a' = (v + p[idx] * (v > 0)) * s[idx]  (sparse_coder.py:136-140)
+        off = 0
+        for st in self.live:
+            li = self.coders[st.layer]
+            t = st.slot
+            k = st.idx.shape[1]
+            ga = ga_cat[:, off:off + k]
+            off += k
+            loc = (st.idx - li.lat_begin).clamp_(0, li.m_local - 1)  # (entries of other shards carry ga = 0)
+            vf = st.v.float()
+            pos = (vf > 0).float()
+            ps = li.post_enc_scales[t] if li.post_enc_scales is not None else None
+            u = ga * ps[loc] if ps is not None else ga
+            st.gv += u
+            if li.post_encs[t].requires_grad:
+                if st.seg is None:
+                    st.seg = ops.segments_build(st.idx, li.m_local, lat_begin=li.lat_begin)
+                if ps is not None and ps.requires_grad:
+                    gp, gs = ops.segment_sum(st.seg, (u * pos).view(-1), (ga * (vf + li.post_encs[t][loc] * pos)).reshape(-1))
+                    self._acc_grad(ps, gs)
+                else:
+                    gp, _ = ops.segment_sum(st.seg, (u * pos).view(-1))
+                self._acc_grad(li.post_encs[t], gp)
+        return sc[0]
+
+    @torch.no_grad()
+    def _advance(self, acc_steps: int):
+        """Advance every live source to its next target; deferred encoder backward of the sources that just wrote their
+        last one (runner.py:56-59, 193-197; fused_encoder.py:92-155)."""
+        ops = self.ops
         still = []
         for st in self.live:
             li = self.coders[st.layer]
@@ -678,9 +781,6 @@ class CLTEngine:
             else:
                 still.append(st)
         self.live = still
-        self.last_fvu[j] = fvu
-        self.last_idx[j] = idx if enc.get("fired") is None else enc["fired"]  # merged global indices (trainer.py:622-628)
-        return fvu
 
     def _fused_state(self, p: Tensor, acc_steps: int):
         """Optimizer state / hyper-parameters for applying this step's update of ``p`` inside the gradient kernel, or

@@ -88,7 +88,7 @@ def test_fvu_stages_equal_fused(ops, masked):
     torch.testing.assert_close(torch.cat([outs[0][1], outs[1][1]]), G, rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("case", ["clt", "sae"])
+@pytest.mark.parametrize("case", ["clt", "sae", "concat"])
 def test_engine_tp1_vs_oracle(case):
     """The explicit engine on the HIP kernels (tp = 1), 3 train steps incl. step-0 init, Adam and schedule."""
     import sys
@@ -98,7 +98,7 @@ def test_engine_tp1_vs_oracle(case):
     from clt_training_amd.engine import ShardedCoder
     from clt_training_amd.tp import TPTrainer
 
-    sae_kw, L, cross = CASES["clt_skip_scale_norm_div" if case == "clt" else "sae"]
+    sae_kw, L, cross = CASES[dict(clt="clt_skip_scale_norm_div", sae="sae", concat="clt_concat_scale_norm")[case]]
     d, N = 16, 24
     saes, steps = _make_problem(sae_kw, L, cross, d, N)
     hooks = [f"h.{i}" for i in range(L)]
@@ -118,7 +118,8 @@ def test_engine_tp1_vs_oracle(case):
         batch["loss_mask"] = m.to(DEV)
         got = tr.step(batch)
         r = O.clt_train_step(layers, xs, ys, m, sae_kw["k"], normalize_io=sae_kw.get("normalize_io", False),
-                             divide_cross_layer=sae_kw.get("divide_cross_layer", False))
+                             divide_cross_layer=sae_kw.get("divide_cross_layer", False),
+                             coalesce=sae_kw.get("coalesce_topk", "none"))
         torch.testing.assert_close(torch.tensor([float(got[h]) for h in hooks]), torch.stack(r.fvus), rtol=2e-4, atol=1e-6)
         lr = 1e-2 * O.warmup_linear_factor(s, 2, 4)
         for l, lp in enumerate(layers):
@@ -128,6 +129,7 @@ def test_engine_tp1_vs_oracle(case):
                 tensors[f"b_decs.{i}"] = lp.b_decs[i]
                 if lp.W_skips[i] is not None:
                     tensors[f"W_skips.{i}"] = lp.W_skips[i]
+            for i in range(len(lp.post_encs)):
                 tensors[f"post_encs.{i}"] = lp.post_encs[i]
                 if lp.post_enc_scales is not None:
                     tensors[f"post_enc_scales.{i}"] = lp.post_enc_scales[i]
@@ -143,6 +145,7 @@ def test_engine_tp1_vs_oracle(case):
         for i in range(len(lp.W_decs)):
             torch.testing.assert_close(c.W_decs[i].detach().cpu(), lp.W_decs[i], rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(c.b_decs[i].detach().cpu(), lp.b_decs[i], rtol=1e-4, atol=1e-5)
+        for i in range(len(lp.post_encs)):
             torch.testing.assert_close(c.post_encs[i].detach().cpu(), lp.post_encs[i], rtol=1e-4, atol=1e-5)
 
 
@@ -249,3 +252,42 @@ def test_engine_fast_path_equals_separate_kernels_at_config_widths(monkeypatch, 
         # routes' bf16-level gradient differences into percent-level differences on near-zero gradient elements
         # (tests/test_gpu_tp_shapes.py bounds the same quantity against the oracle at 0.15).
         assert err < (1e-2 if float(p0[n].norm()) > 0 else 5e-2), (n, err)
+
+
+@pytest.mark.parametrize("name", ["clt_none_L3", "clt_none_div_scale_norm_L4", "clt_concat_L3"])
+def test_engine_vs_reference_golden(name):
+    """The explicit engine (the path bench.py times; plain-gradient route, no optimizer attached) directly against the
+    golden vectors the REFERENCE produced for the hook sequence of trainer.py:598-682: FVU per layer, reconstruction,
+    merged indices and the gradient of every parameter, fp32, rtol 1e-5.  clt_concat_L3 is BASELINE configs[4]'s mode
+    (coalesce_topk="concat", post_encoder_scale, normalize_io)."""
+    import sys
+    sys.path.insert(0, "tests")
+    from conftest import golden_grad_name, load_golden
+    from test_gpu_clt import build_sae
+    from clt_training_amd import TrainConfig, hip_ops
+    from clt_training_amd.engine import CLTEngine, ShardedCoder
+
+    t, meta = load_golden(name)
+    L = meta["L"]
+    saes = [build_sae(t, meta, l, False) for l in range(L)]
+    coders = [ShardedCoder.from_full(s, 0, 1, DEV) for s in saes]
+    eng = CLTEngine(TrainConfig(sae=saes[0].cfg, hookpoints=[f"h.{i}" for i in range(L)], cross_layer=meta["cross_layer"]),
+                    coders, hip_ops)
+    eng.keep_outputs = True
+    eng.reset()
+    eng.begin_step(packed=True)
+    mask = t["mask"].to(DEV)
+    for l in range(L):
+        fvu = eng.layer_step(l, t[f"x.{l}"].to(DEV), t[f"y.{l}"].to(DEV), mask)
+        torch.testing.assert_close(fvu.cpu(), t[f"fvu.{l}"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(eng.last_out[l].float().cpu(), t[f"sae_out.{l}"], rtol=1e-5, atol=1e-5)
+        _, gi = O.topk_merge(torch.zeros(eng.last_idx[l].shape), eng.last_idx[l].cpu(), eng.last_idx[l].shape[1])
+        assert torch.equal(gi.sort(1).values, t[f"idx.{l}"].sort(1).values)
+    assert not eng.live
+    for l, c in enumerate(coders):
+        want = {golden_grad_name(k[len(f"g.{l}."):]): v for k, v in t.items() if k.startswith(f"g.{l}.")}
+        got = dict(c.named_parameters())
+        assert set(want) == set(got), (sorted(want), sorted(got))
+        for n, ref in want.items():
+            assert got[n].grad is not None, (l, n)
+            torch.testing.assert_close(got[n].grad.float().cpu(), ref, rtol=1e-5, atol=2e-7, msg=lambda m: f"{l}.{n}: {m}")

@@ -59,13 +59,15 @@ def _oracle_layers(saes):
     layers = []
     for sae in saes:
         T = max(1, sae.cfg.n_targets if sae.cfg.transcode else 1)
+        Td = 1 if sae.cfg.coalesce_topk == "concat" else T  # concat: one decoder / bias / skip per layer
         sd = {n: p.detach().clone() for n, p in sae.state_dict().items()}
 
         def lst(stem, plural):
-            return [sd[stem if (i == 0 and stem in sd) else f"{plural}.{i}"] for i in range(T)]
+            n = T if stem.startswith("post_enc") else Td
+            return [sd[stem if (i == 0 and stem in sd) else f"{plural}.{i}"] for i in range(n)]
 
         scales = lst("post_enc_scale", "post_enc_scales") if sae.cfg.post_encoder_scale else None
-        skips = lst("W_skip", "W_skips") if sae.cfg.skip_connection else [None] * T
+        skips = lst("W_skip", "W_skips") if sae.cfg.skip_connection else [None] * Td
         layers.append(O.LayerParams(sd["encoder.weight"], sd["encoder.bias"], lst("W_dec", "W_decs"), lst("b_dec", "b_decs"),
                                     skips, lst("post_enc", "post_encs"), scales, sae.cfg.n_targets,
                                     sd.get("in_norm"), sd.get("out_norm"), sae.cfg.transcode))
@@ -136,6 +138,9 @@ CASES = {
     "clt_groupmax": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True, activation="groupmax"), 3, 3),
     # fused_encoder.py:204-240, 315-318: row top-4k, merge, batch-wide threshold on the merged rows
     "clt_batchtopk": (dict(transcode=True, expansion_factor=4, k=2, skip_connection=True, activation="batchtopk"), 3, 2),
+    # BASELINE configs[4]: per-target tied decoder, one bag of k * n_live candidates per token (runner.py:93-127)
+    "clt_concat_scale_norm": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True, post_encoder_scale=True,
+                                   normalize_io=True, coalesce_topk="concat"), 3, 3),
     # optimizer="signum" with force_lr_warmup: SignSGD (sign_sgd.py:19-23) + the linear warm-up (trainer.py:224-250)
     "clt_signum": (dict(transcode=True, expansion_factor=4, k=4, skip_connection=True), 3, 2,
                    dict(optimizer="signum", force_lr_warmup=True, lr=1e-3)),
@@ -162,7 +167,7 @@ def run_case(case, tmp_path, device="cpu", resume=False):
             xs = ys  # an SAE reconstructs its own input (trainer.py:524)
         r = O.clt_train_step(layers, xs, ys, m, sae_kw["k"], normalize_io=sae_kw.get("normalize_io", False),
                              divide_cross_layer=sae_kw.get("divide_cross_layer", False),
-                             activation=sae_kw.get("activation", "topk"))
+                             activation=sae_kw.get("activation", "topk"), coalesce=sae_kw.get("coalesce_topk", "none"))
         want_fvu.append([float(f) for f in r.fvus])
         lr = train_kw.get("lr", 1e-2) * O.warmup_linear_factor(s, 2, 4)
         for l, lp in enumerate(layers):
@@ -172,6 +177,7 @@ def run_case(case, tmp_path, device="cpu", resume=False):
                 tensors[f"b_decs.{i}"] = lp.b_decs[i]
                 if lp.W_skips[i] is not None:
                     tensors[f"W_skips.{i}"] = lp.W_skips[i]
+            for i in range(len(lp.post_encs)):
                 tensors[f"post_encs.{i}"] = lp.post_encs[i]
                 if lp.post_enc_scales is not None:
                     tensors[f"post_enc_scales.{i}"] = lp.post_enc_scales[i]
@@ -195,9 +201,12 @@ def run_case(case, tmp_path, device="cpu", resume=False):
             for i in range(len(lp.W_decs)):
                 torch.testing.assert_close(st[f"{l}.W_decs.{i}"], lp.W_decs[i][lo:hi], rtol=1e-4, atol=1e-5)
                 torch.testing.assert_close(st[f"{l}.b_decs.{i}"], lp.b_decs[i], rtol=1e-4, atol=1e-5)
-                torch.testing.assert_close(st[f"{l}.post_encs.{i}"], lp.post_encs[i][lo:hi], rtol=1e-4, atol=1e-5)
                 if lp.W_skips[i] is not None:
                     torch.testing.assert_close(st[f"{l}.W_skips.{i}"], lp.W_skips[i], rtol=1e-4, atol=1e-5)
+            for i in range(len(lp.post_encs)):
+                torch.testing.assert_close(st[f"{l}.post_encs.{i}"], lp.post_encs[i][lo:hi], rtol=1e-4, atol=1e-5)
+                if lp.post_enc_scales is not None:
+                    torch.testing.assert_close(st[f"{l}.post_enc_scales.{i}"], lp.post_enc_scales[i][lo:hi], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("case", list(CASES))
