@@ -306,11 +306,15 @@ def main():
             from oracle import cpu_baseline
 
             cpu = cpu_baseline.run(L=2, d=d, M=M, k=k, N=1024, min_seconds=args.cpu_seconds, full_L=L)
+            cpu["c1"] = cpu_baseline.run_c1(min_seconds=6.0)  # BASELINE configs[0], whole steps, not extrapolated
         line = {
             "metric": "train tokens/sec, GPT-2 CLT (exp128,k32) fwd+bwd+Adam", "value": round(value, 1),
             "unit": "tokens/s", "n_gpus": real_world, "simulated": args.simulate_tp > 1 and real_world == 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "host_issue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            # wall time the host spent enqueueing the timed steps.  It INCLUDES back-pressure: the HIP queue is bounded, so
+            # once the host is a few hundred launches ahead of a GPU-bound step its launch calls block.  The pure host
+            # cost of this launch sequence is ~21 ms/step (tools/host_profile.py: same sequence, tiny kernels).
+            "host_enqueue_wall_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": f"GPT-2 small CLT: {L} layers, cross_layer={L}, d={d}, latents={M}, k={k}, "
                                    f"skip_connection, {args.dtype} weights, {'Adam' if args.optimizer == 'adam' else 'SignSGD'}{'' if args.activation == 'topk' else ', ' + args.activation}; {N} tokens/step/GPU "

@@ -42,6 +42,12 @@ class Adam(torch.optim.Optimizer):
         for cache in ("_group_of", "_by_ptr"):
             self.__dict__.pop(cache, None)
 
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        for cache in ("_group_of", "_by_ptr"):
+            self.__dict__.pop(cache, None)
+        self._tables = {}
+
     def _state(self, p):
         st = self.state[p]
         if not st:

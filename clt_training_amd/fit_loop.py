@@ -138,8 +138,15 @@ class FitLoop:
         # hand-set ``wandb_log`` sink goes on every rank or on none.
         do_log = cfg.log_to_wandb or self.wandb_log is not None
         dataset = self.dataset
-        if self.global_step > 0 and not cfg.restart_epoch and hasattr(dataset, "skip"):
-            dataset = dataset.skip(self.global_step)  # trainer.py:410-417
+        if self.global_step > 0 and not cfg.restart_epoch:  # trainer.py:410-417 (the reference asserts ``select``)
+            if hasattr(dataset, "skip"):
+                dataset = dataset.skip(self.global_step)
+            elif hasattr(dataset, "__getitem__") and hasattr(dataset, "__len__"):
+                dataset = [dataset[i] for i in range(self.global_step, len(dataset))]
+            else:
+                import itertools
+
+                dataset = itertools.islice(iter(dataset), self.global_step, None)  # plain iterables of step dicts
         denom = cfg.grad_acc_steps * cfg.micro_acc_steps * cfg.wandb_log_frequency
         avg_fvu = {}
         for batch in dataset:
@@ -164,6 +171,8 @@ class FitLoop:
             if log is not None:
                 log(self.global_step, fvus)
         self.save()  # trainer.py:861
+        if cfg.save_best and avg_fvu:  # trainer.py:862-863
+            self.save_best({n: float(v) for n, v in avg_fvu.items()})
         return self
 
     def save_best(self, avg_loss: dict):

@@ -6,12 +6,24 @@ None).  A matrix that enters more than one Function in a step (weight tying) is 
 ``.grad`` -> ``step()`` route."""
 from __future__ import annotations
 
+import weakref
+
 ACTIVE = None      # adam.Adam, or None: no fusion
 _uses: dict = {}   # data_ptr -> number of forward uses since begin_step()
-_project: set = set()  # data_ptrs of unit-norm SAE decoders: project the gradient row first (sparse_coder.py:696-711)
+# unit-norm SAE decoders: project the gradient row first (sparse_coder.py:696-711).  Keyed by weak references to the
+# parameter objects (a freed and reused allocation must not inherit the flag); looked up through their CURRENT storage.
+_project: "weakref.WeakSet" = weakref.WeakSet()
 
 
 def begin_step():
+    _uses.clear()
+
+
+def end_step():
+    """After the optimizer step: no Function outside Trainer.step may take the fused branch (an evaluation with
+    gradients, a second model) -- it would apply an in-place Adam update and return no weight gradient."""
+    global ACTIVE
+    ACTIVE = None
     _uses.clear()
 
 
@@ -22,7 +34,11 @@ def note_use(t):
 
 
 def set_project(t, on: bool = True):
-    (_project.add if on else _project.discard)(t.data_ptr())
+    (_project.add if on else _project.discard)(t)
+
+
+def _projected(ptr: int) -> bool:
+    return any(p.data_ptr() == ptr for p in _project)
 
 
 def fused_for(t):
@@ -30,6 +46,6 @@ def fused_for(t):
     if ACTIVE is None or _uses.get(t.data_ptr(), 0) != 1:
         return None
     h = ACTIVE.fused_rows_by_ptr(t.data_ptr())
-    if h is not None and t.data_ptr() in _project:
+    if h is not None and _projected(t.data_ptr()):
         h = dict(h, project=True)
     return h

@@ -82,8 +82,11 @@ _ws_cache: dict = {}
 
 
 def workspace(device, nbytes: int, tag: str = "default") -> Tensor:
-    """Grow-only per-device scratch buffer (stream-ordered reuse on the current stream)."""
-    key = (device, tag)
+    """Grow-only scratch buffer per (device, tag, CURRENT STREAM): reuse is stream-ordered, so two streams never share
+    a buffer (tp.TPTrainer runs the encoder half of the next layer on a side stream), and a buffer that is replaced by
+    a larger one was allocated on the only stream that ever used it -- the caching allocator may hand it out again."""
+    device = torch.device(device)
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -142,6 +142,12 @@ class Trainer(FitLoop):
         acc_steps = self.cfg.grad_acc_steps * self.cfg.micro_acc_steps
         fused_state.ACTIVE = self.optimizers[0] if self._fused else None
         fused_state.begin_step()
+        try:
+            return self._step(batch, acc_steps)
+        finally:
+            fused_state.end_step()
+
+    def _step(self, batch: dict, acc_steps: int):
         self.runner.reset()
         loss_mask = batch.get("loss_mask")
         n_tok = 0

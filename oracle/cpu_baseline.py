@@ -80,7 +80,7 @@ def train_step(layers, xs, ys, mask, k, opt):
     return [float(f) for f in fvus]
 
 
-def run(L=2, d=768, M=98304, k=32, N=1024, min_seconds=10.0, max_steps=50, full_L=12):
+def _time_steps(L, d, M, k, N, min_seconds, max_steps):
     torch.manual_seed(0)
     layers = make_layers(L, d, M, cross=L)
     params = [p for lp in layers for n, p in lp.items() if n != "T"]
@@ -94,7 +94,22 @@ def run(L=2, d=768, M=98304, k=32, N=1024, min_seconds=10.0, max_steps=50, full_
     while steps < max_steps and (time.perf_counter() - t0 < min_seconds or steps < 2):
         train_step(layers, xs, ys, mask, k, opt)
         steps += 1
-    dt = time.perf_counter() - t0
+    return steps, time.perf_counter() - t0
+
+
+def run_c1(min_seconds=6.0):
+    """BASELINE.json configs[0] / BASELINE.md section 3, UN-EXTRAPOLATED: the single-layer transcoder (d=768, expansion 32,
+    k=32, skip connection, fp32) as whole fwd + bwd + Adam steps on the host cores, at N = 1024 and N = 8192."""
+    out = {}
+    for N in (1024, 8192):
+        steps, dt = _time_steps(1, 768, 24576, 32, N, min_seconds / 2, 20)
+        out[f"N{N}"] = dict(tokens_per_s=round(N * steps / dt, 1), steps=steps, seconds=round(dt, 2))
+    return dict(config="configs[0]: single-layer transcoder d=768, latents=24576, k=32, fp32, whole steps (not extrapolated)",
+                cores=torch.get_num_threads(), **out)
+
+
+def run(L=2, d=768, M=98304, k=32, N=1024, min_seconds=10.0, max_steps=50, full_L=12):
+    steps, dt = _time_steps(L, d, M, k, N, min_seconds, max_steps)
     pairs = L * (L + 1) // 2
     full_pairs = full_L * (full_L + 1) // 2
     return dict(value=N * steps / dt, unit="tokens/s", cores=torch.get_num_threads(), kind="port",

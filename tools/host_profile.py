@@ -23,6 +23,16 @@ tr = (TPTrainer if path == "engine" else Trainer)(cfg, batches, device=dev, num_
 for s in range(3):
     tr.step(batches[s % 2])
 torch.cuda.synchronize()
+import time  # noqa: E402
+
+t0 = time.perf_counter()
+for s in range(10):
+    tr.step(batches[s % 2])
+t_issue = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"host issue {t_issue * 100:.2f} ms/step, wall {t_all * 100:.2f} ms/step (same launch sequence as C2: {L} layers, "
+      f"{L * (L + 1) // 2} pairs; tables 16x smaller and {N} tokens, so the GPU never back-pressures the host)")
 pr = cProfile.Profile()
 pr.enable()
 for s in range(5):

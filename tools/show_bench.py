@@ -6,7 +6,7 @@ for f in sys.argv[1:]:
     for line in open(f):
         if line.startswith("{"):
             j = json.loads(line)
-            print(f, j["value"], "tok/s", j["ms_per_step"], "ms host", j["host_issue_ms_per_step"], j["config"]["parallelism"])
+            print(f, j["value"], "tok/s", j["ms_per_step"], "ms host", j["host_enqueue_wall_ms_per_step"], j["config"]["parallelism"])
             tot = 0.0
             for k, v in j["kernels"].items():
                 tot += v["ms_per_step"]
