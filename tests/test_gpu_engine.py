@@ -138,15 +138,18 @@ def test_engine_tp1_vs_oracle(case):
                 pn, mm, vv = O.adam_step(p, r.grads[l][n], mm, vv, s + 1, lr)
                 p.copy_(pn.float())
                 state[l][n] = (mm, vv)
+    # three Adam steps at lr 1e-2: g / (sqrt(v) + eps) turns fp32 accumulation-order noise on a near-zero gradient element
+    # into a visible fraction of lr on that element, hence the absolute floor of 5e-3 * lr
+    tol = dict(rtol=1e-4, atol=5e-5)
     for l, lp in enumerate(layers):
         c = coders[l]
-        torch.testing.assert_close(c.W_enc.detach().cpu(), lp.W_enc, rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(c.b_enc.detach().cpu(), lp.b_enc, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(c.W_enc.detach().cpu(), lp.W_enc, **tol)
+        torch.testing.assert_close(c.b_enc.detach().cpu(), lp.b_enc, **tol)
         for i in range(len(lp.W_decs)):
-            torch.testing.assert_close(c.W_decs[i].detach().cpu(), lp.W_decs[i], rtol=1e-4, atol=1e-5)
-            torch.testing.assert_close(c.b_decs[i].detach().cpu(), lp.b_decs[i], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(c.W_decs[i].detach().cpu(), lp.W_decs[i], **tol)
+            torch.testing.assert_close(c.b_decs[i].detach().cpu(), lp.b_decs[i], **tol)
         for i in range(len(lp.post_encs)):
-            torch.testing.assert_close(c.post_encs[i].detach().cpu(), lp.post_encs[i], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(c.post_encs[i].detach().cpu(), lp.post_encs[i], **tol)
 
 
 def test_fused_row_adam_equals_grad_then_adam(monkeypatch):
