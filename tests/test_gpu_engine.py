@@ -293,4 +293,8 @@ def test_engine_vs_reference_golden(name):
         assert set(want) == set(got), (sorted(want), sorted(got))
         for n, ref in want.items():
             assert got[n].grad is not None, (l, n)
-            torch.testing.assert_close(got[n].grad.float().cpu(), ref, rtol=1e-5, atol=2e-7, msg=lambda m: f"{l}.{n}: {m}")
+            # rtol 1e-5 with an absolute floor of 1e-5 x the tensor's largest magnitude: an element that is a sum with
+            # cancellation (the library GEMMs behind the skip-matrix gradients accumulate in an order that depends on
+            # the kernel the library picks on the box) carries an error relative to its terms
+            atol = max(2e-7, 1e-5 * float(ref.abs().max()))
+            torch.testing.assert_close(got[n].grad.float().cpu(), ref, rtol=1e-5, atol=atol, msg=lambda m: f"{l}.{n}: {m}")
