@@ -107,6 +107,34 @@ def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.
     return None, None
 
 
+def host_launch_cost(args, device, steps=10):
+    """Pure host cost of one step's launch sequence, ms: the SAME sequence (layers, pairs, routes) on a twin whose
+    tables are 16x smaller and whose batch is 256 tokens, so the GPU finishes each step long before the host has
+    issued the next one and no launch call ever blocks on a full queue."""
+    from clt_training_amd import SparseCoderConfig, TrainConfig
+    from clt_training_amd.tp import TPTrainer
+
+    L, d = args.layers, args.d_model
+    hooks = [f"h.{i}.mlp" for i in range(L)]
+    sae_cfg = SparseCoderConfig(dtype=args.dtype if args.dtype == "bfloat16" else "none", expansion_factor=8, k=args.k,
+                                transcode=not args.sae, skip_connection=not args.sae, activation=args.activation,
+                                coalesce_topk=args.coalesce, post_encoder_scale=args.coalesce == "concat")
+    cfg = TrainConfig(sae=sae_cfg, hookpoints=hooks, cross_layer=0 if args.sae else L, optimizer=args.optimizer, lr=2e-4,
+                      lr_warmup_steps=50, log_to_wandb=False, force_lr_warmup=args.optimizer == "signum")
+    act_dtype = torch.bfloat16 if args.dtype == "bfloat16" else torch.float32
+    batches = synth_batches(hooks, 256, d, 2, act_dtype, device)
+    twin = TPTrainer(cfg, batches, device=device, num_batches=10_000)
+    for i in range(3):
+        twin.step(batches[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        twin.step(batches[i % 2])
+    t = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return t / steps * 1e3
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run
     (one rank per GPU, rendezvous on 127.0.0.1) as a CHILD process and return its exit code.  Nothing in this
@@ -159,6 +187,7 @@ def main():
                     help="concat = BASELINE configs[4]: per-target tied decoder (one W_dec per layer), post_encoder_scale; "
                          "a secondary data point, not the metric")
     ap.add_argument("--routes-off", default="", help="A/B timing only: comma-separated engine.ROUTES switches to turn off")
+    ap.add_argument("--routes-on", default="", help="A/B timing only: engine.ROUTES switches that are off by default")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -191,6 +220,9 @@ def main():
     for name in filter(None, args.routes_off.split(",")):
         assert hasattr(ROUTES, name), name
         setattr(ROUTES, name, False)
+    for name in filter(None, args.routes_on.split(",")):
+        assert hasattr(ROUTES, name), name
+        setattr(ROUTES, name, True)
 
     L, d, k = args.layers, args.d_model, args.k
     M = d * args.expansion
@@ -300,6 +332,9 @@ def main():
         roof_s = flops / PEAK_BF16 + hbm / PEAK_HBM
         step_roofline = {"ms": round(roof_s * 1e3, 3), "frac": round(roof_s / (dt / args.steps), 4),
                          "tokens_per_s_at_roofline": round(tokens_per_step / roof_s, 1)}
+        host_ms = None
+        if real_world == 1 and args.simulate_tp <= 1 and args.path == "engine":
+            host_ms = round(host_launch_cost(args, device), 3)
         cpu = None
         if not args.no_cpu_baseline and real_world == 1:  # rank 0 at N = 1 only
             sys.path.insert(0, str(ROOT))
@@ -313,8 +348,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             # wall time the host spent enqueueing the timed steps.  It INCLUDES back-pressure: the HIP queue is bounded, so
             # once the host is a few hundred launches ahead of a GPU-bound step its launch calls block.  The pure host
-            # cost of this launch sequence is ~21 ms/step (tools/host_profile.py: same sequence, tiny kernels).
-            "host_enqueue_wall_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            # cost of this launch sequence is host_launch_ms_per_step (host_launch_cost: same sequence, tiny kernels).
+            "host_enqueue_wall_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "host_launch_ms_per_step": host_ms,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": f"GPT-2 small CLT: {L} layers, cross_layer={L}, d={d}, latents={M}, k={k}, "
                                    f"skip_connection, {args.dtype} weights, {'Adam' if args.optimizer == 'adam' else 'SignSGD'}{'' if args.activation == 'topk' else ', ' + args.activation}; {N} tokens/step/GPU "

@@ -49,6 +49,7 @@ class Routes:
     rows_pass: bool = True   # decoder backward as one row pass per pair (clt_decode_bwd_rows*)
     fused_adam: bool = True  # Adam applied inside the gradient kernels
     overlap: bool = True     # tp > 1: encoder half of layer j + 1 on a side stream
+    overlap_single: bool = False  # the same at world 1 (no collectives to hide; measured)
     graph: bool = True       # capture the step in a HIP graph where the trainer supports it
     pack: bool = True        # per-step packing of the skip matrices / decoder biases of all (source, target) pairs
 

@@ -91,8 +91,8 @@ class TPTrainer(FitLoop):
         # exchange) is enqueued on a side stream before the decoder / backward half of layer j on the main stream, so
         # the collectives of either half run behind the kernels of the other.  Step 0 (data-dependent init) is serial.
         names = cfg.hookpoints
-        overlap = (self.comm.world > 1 and self.device.type == "cuda" and self.global_step > 0
-                   and ROUTES.overlap)
+        overlap = ((self.comm.world > 1 or ROUTES.overlap_single) and self.device.type == "cuda"
+                   and self.global_step > 0 and ROUTES.overlap)
         pending = {}
         if overlap:
             main = torch.cuda.current_stream(self.device)
