@@ -250,3 +250,104 @@ def test_gpu_engine_vs_reference_trainer(name):
         return {n.replace("W_enc", "W_enc").replace("b_enc", "b_enc"): p for n, p in c.named_parameters()}
 
     _gpu_check(tr, t, meta, tensors)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["autograd", "engine"])
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_model_driven_fit_vs_oracle_and_reference(name, which, tmp_path):
+    """the SAME random-init GPT-2 and token ids the reference run used (rebuilt from the
+    recorded seed) drive ``fit`` on the GPU through the forward hooks.  (i) the activations the hooks hand to the step
+    equal the ones the reference's hooks saw (GPU vs CPU forward: rtol 1e-4); (ii) the trained parameters and the
+    fired-latent counters equal the ORACLE's run over exactly those recorded activations (fp32 tolerance, Adam floor);
+    (iii) they also track the reference Trainer's own final parameters (looser: the activations differ in the last bits
+    and Adam's first steps amplify that on near-zero gradient elements)."""
+    transformers = pytest.importorskip("transformers")
+    import clt_training_amd.sparse_coder as sc
+    from clt_training_amd import Trainer
+    from clt_training_amd.tp import TPTrainer
+    from dataclasses import replace
+
+    t, meta = load_golden(name)
+    L, d, steps, seed, cfgd = meta["L"], meta["d"], meta["steps"], meta["seed"], meta["cfg"]
+    T, B = 16, 2
+    assert meta["tokens_per_step"] == B * T
+    torch.manual_seed(seed)  # as make_golden.golden_trainer
+    gcfg = transformers.GPT2Config(n_layer=L, n_embd=d, n_head=2, vocab_size=96, n_positions=T, bos_token_id=0,
+                                   eos_token_id=0)
+    model = transformers.GPT2LMHeadModel(gcfg).eval().to("cuda")
+    g = torch.Generator().manual_seed(seed + 1)
+    ids = torch.randint(1, 96, (B * steps, T), generator=g)
+    rows = [{"input_ids": r} for r in ids]
+    cfg = replace(make_cfg(meta, ["h.*.mlp"]), remove_first_token=True, filter_bos=True, batch_size=B,
+                  save_dir=str(tmp_path), run_name="run", save_every=10**9)
+    old, sc.AUTOCAST_ENABLED = sc.AUTOCAST_ENABLED, False
+    try:
+        tr = (Trainer if which == "autograd" else TPTrainer)(cfg, rows, model)
+        assert list(tr.saes) == meta["hooks"]
+        with torch.no_grad():  # device RNG differs from the CPU's: start from the reference's parameters
+            for l, h in enumerate(meta["hooks"]):
+                own = {golden_grad_name(n): p for n, p in tr.saes[h].named_parameters()}
+                for n, v in snapshot(t, "p0", l).items():  # (reference names -> oracle names: encoder.weight -> W_enc)
+                    if n in own:  # (buffers such as in_norm / out_norm are set by the step-0 init)
+                        own[n].copy_(v)
+        seen = []
+        step = tr.step
+
+        def recording_step(batch):
+            seen.append({k: (tuple(x.detach().clone() for x in v) if isinstance(v, tuple) else v.detach().clone())
+                         for k, v in batch.items()})
+            return step(batch)
+
+        tr.step = recording_step
+        tr.fit()
+    finally:
+        sc.AUTOCAST_ENABLED = old
+    assert tr.global_step == steps and len(seen) == steps
+    transcode = cfgd.get("transcode", False)
+    # (i) what the hooks recorded
+    for s, b in enumerate(seen):
+        assert torch.equal(b["loss_mask"].cpu().flatten(), t["mask"])
+        for l, h in enumerate(meta["hooks"]):
+            x, y = b[h]
+            torch.testing.assert_close(y.float().cpu(), t[f"y{s}.{l}"], rtol=1e-4, atol=1e-5)
+            if transcode:
+                torch.testing.assert_close(x.float().cpu(), t[f"x{s}.{l}"], rtol=1e-4, atol=1e-5)
+    # (ii) the oracle over exactly those activations
+    nio = cfgd.get("normalize_io", False)
+    sae_unit = not transcode and cfgd.get("normalize_decoder", True)
+    layers = golden_layers(t, meta, L, prefix="p0")
+    since = [torch.zeros(lp.W_enc.shape[0], dtype=torch.long) for lp in layers]
+    state = [dict() for _ in range(L)]
+    for s, b in enumerate(seen):
+        ys = [b[h][1].float().cpu() for h in meta["hooks"]]
+        xs = [b[h][0].float().cpu() for h in meta["hooks"]] if transcode else ys
+        if s == 0:
+            for l in range(L):
+                O.step0_init(layers[l], xs[l], ys[l], nio)
+        if sae_unit:
+            for lp in layers:
+                lp.W_decs[0] = O.unit_norm_decoder(lp.W_decs[0].double()).float()
+        r = O.clt_train_step(layers, xs, ys, t["mask"], cfgd["k"], normalize_io=nio,
+                             divide_cross_layer=cfgd.get("divide_cross_layer", False))
+        if sae_unit:
+            for l, lp in enumerate(layers):
+                r.grads[l]["W_decs.0"] = O.remove_parallel_grad(lp.W_decs[0].double(), r.grads[l]["W_decs.0"])
+        lr = meta["lr"] * O.warmup_linear_factor(s, meta["warmup"], meta["num_batches"])
+        for l, lp in enumerate(layers):
+            for n, p in oracle_tensors(lp).items():
+                mm, vv = state[l].get(n, (torch.zeros_like(p).double(), torch.zeros_like(p).double()))
+                pn, mm, vv = O.adam_step(p, r.grads[l][n], mm, vv, s + 1, lr, b1=meta["b1"])
+                p.copy_(pn.float())
+                state[l][n] = (mm, vv)
+            since[l] += meta["tokens_per_step"]
+            since[l][r.top_idx[l].flatten()] = 0
+    for l, h in enumerate(meta["hooks"]):
+        got = {golden_grad_name(n): p.detach().float().cpu() for n, p in tr.saes[h].named_parameters()}
+        for n, p in oracle_tensors(layers[l]).items():
+            close(got[n], p, f"oracle, final {l}.{n}", floor=1e-3 * meta["lr"])
+        assert torch.equal(tr.num_tokens_since_fired[h].cpu(), since[l]), l
+        # (iii) and the reference Trainer's own end state
+        want = snapshot(t, f"after{steps - 1}", l)
+        for n, p in got.items():
+            close(p, want[n], f"reference, final {l}.{n}", rtol=1e-3, floor=0.25 * meta["lr"])
