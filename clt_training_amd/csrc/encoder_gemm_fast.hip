@@ -36,11 +36,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int ROWB = 64;                    // bytes of K per row per k-step (32 bf16)
 constexpr int OP_BYTES = GEMM_TM * ROWB;    // 16 KiB per operand per stage
 constexpr int NSTAGE = 4;
-constexpr int AUX_OFF = 2 * OP_BYTES;     // per stage and wave 1 KiB: [0, 256) bias of 64 latents, [512, 1024) tau of 128 tokens
-constexpr int STAGE_BYTES = 2 * OP_BYTES + 4096;
+constexpr int AUX_OFF = 2 * OP_BYTES;     // per stage and wave 768 B: [0, 256) bias of 64 latents, [256, 768) tau of 128 tokens
+constexpr int AUX_WAVE = 768;
+constexpr int STAGE_BYTES = 2 * OP_BYTES + 4 * AUX_WAVE;
 constexpr int NTHREADS = 256;
 constexpr int NDMA = 9;                     // LDS-DMAs per wave per stage: 4 W pieces, 4 x pieces, 1 bias/tau piece
-constexpr int QLANE = 16;                   // filter mode: hit-queue entries per LANE and tile (4 KiB per wave)
+constexpr int QLANE = 10;                   // filter mode: 8-byte hit-queue entries per LANE and tile (5 KiB per wave)
 constexpr int NSTORE = 64;                  // store instructions per wave in the epilogue of an interior tile
 
 #define CLT_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -98,7 +99,7 @@ __host__ __device__ __forceinline__ int lt_actual(int v, int mode, int S) {
 // MODE 0: store relu(pre) (OT = bf16 or f32).  MODE 1: per-token threshold filter, no pre matrix (see FastArgs).
 template <typename OT, int MODE>
 __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE_BYTES + (MODE == 1 ? 4 * QLANE * 64 * 4 : 0)];
+  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE_BYTES + (MODE == 1 ? 4 * QLANE * 64 * 8 : 0)];
   int ntt = p.ntt;
   if (p.gate) {  // fallback launch: runs only if the fused path raised a flag
     const int flagged = *p.gate;
@@ -148,10 +149,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
   int ld_t = 0, ld_ks = 0, ld_slot = 0;
   const char* ldW = Wb;
   const char* ldX = xb;
-  const char* ldA = zero;  // per-lane source of the aux piece: bias chunk (lanes < nl) or tau chunk (lanes >= 32)
+  const char* ldA = zero;  // per-lane source of the aux piece: bias chunk (lanes < nl <= 16) or tau chunk (lanes 16 .. 47)
   uint32_t voffW[4], voffX[4];
   const int nl = 64 * bias_esize / 16;  // lanes of the bias piece (this wave's 64 latents)
-  const bool aux_lane = lane < nl || (MODE == 1 && lane >= 32);
+  const bool aux_lane = lane < nl || (MODE == 1 && lane >= 16 && lane < 48);
   auto loader_tile = [&](int lt, int tt) {
     const int64_t lat0 = (int64_t)lt_actual(lt, p.lt_mode, p.lt_S) * GEMM_TM, tok0 = (int64_t)tt * GEMM_TN;
     ldW = Wb + lat0 * kbytes;
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
     const int epc = 16 / bias_esize;
     const int64_t lat = lat0 + 64 * wave + lane * epc;
     ldA = (bias && lat + epc <= M) ? bias + lat * bias_esize : zero;
-    if (MODE == 1 && lane >= 32)  // tau is padded to a multiple of 256 tokens
-      ldA = reinterpret_cast<const char*>(p.tau + tok0 + wn * 128 + (lane - 32) * 4);
+    if (MODE == 1 && lane >= 16 && lane < 48)  // tau is padded to a multiple of 256 tokens
+      ldA = reinterpret_cast<const char*>(p.tau + tok0 + wn * 128 + (lane - 16) * 4);
   };
   auto dma = [&](int q, uint32_t stage_lds, int kb0) {
     if (q < 4) {
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
     } else if (q < 8) {
       dma_s(ldX + kb0, voffX[q - 4], stage_lds + OP_BYTES + (wave + 4 * (q - 4)) * 1024);
     } else {
-      if (aux_lane) dma_v(ldA, stage_lds + AUX_OFF + wave * 1024);
+      if (aux_lane) dma_v(ldA, stage_lds + AUX_OFF + wave * AUX_WAVE);  // lane-linear: lane l lands at + 16 l
     }
   };
   auto loader_advance = [&]() {
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int off = wm * 128 + i * 32 + r32;  // latent in the tile: aux piece of wave off / 64
-      const char* bp = st + AUX_OFF + (off >> 6) * 1024 + (off & 63) * bias_esize;
+      const char* bp = st + AUX_OFF + (off >> 6) * AUX_WAVE + (off & 63) * bias_esize;
       float b;
       if (bias_esize == 4) b = *reinterpret_cast<const float*>(bp);
       else b = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(bp));
@@ -336,28 +337,37 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
         //      (bf16 bits << 16 | position in the list's 64 latents), to the private list of this (token, latent
         //      tile, latent half, lane half); the list's length goes to counts.  No atomics, no pre matrix.
         //      Scan: per group of 4 accumulators of one token, 4 reads + max-of-4 + ONE compare + one wave-uniform
-        //      branch (8 instructions; ~half of the groups have no hit in any lane).  A group with a hit runs a short
-        //      INLINE body -- per element an EXEC-masked 4-byte write to a lane-private LDS queue -- so a hit costs
-        //      ~30 instructions that sit next to the scan in the instruction stream; the conversion of queue entries
-        //      into list entries is ONE rolled loop at the end of the tile.  (The first version jumped to 64 unrolled
-        //      out-of-line handlers, ~100 KB of code: every hit group paid an instruction-cache miss, ~300 cycles.)
+        //      branch (9 instructions; ~63 % of the groups have no hit in any lane).  A group with a hit runs a short
+        //      INLINE straight-line body (10 instructions, no EXEC change, no branch per element): EVERY lane writes
+        //      the group's four values, rounded to bf16, as ONE 8-byte entry at its lane-private LDS queue cursor; only
+        //      lanes with a hit advance the cursor and set the group's bit in a 64-bit per-lane mask (a miss is
+        //      overwritten by the next write).  The e-th queue entry of a lane belongs to the e-th set bit of its mask,
+        //      so the entry needs no code.  ONE rolled loop at the end of the tile turns queue entries into list
+        //      entries, testing each of the four values against the threshold's bf16 value (bf16(a) >= v_m is the fp32
+        //      test a >= tau up to the rounding interval's lower edge, which only ever ADDED candidates).
+        //      (History: 64 unrolled out-of-line handlers, ~100 KB of code and an instruction-cache miss per hit group;
+        //      then per-element 4-byte entries with a code, ~33 instructions per hit group.)
         const int list = (cur_lt * 2 + wm) * 2 + h;
         float tl[4];
+        int t16[4];  // (threshold's bf16 value << 16), at least the smallest positive bf16: zeros carry nothing
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t tok = tok0 + wn * 128 + j * 32 + r32;
-          const float t = *reinterpret_cast<const float*>(cb + AUX_OFF + wave * 1024 + 512 + (j * 32 + r32) * 4);
+          const float t = *reinterpret_cast<const float*>(cb + AUX_OFF + wave * AUX_WAVE + 256 + (j * 32 + r32) * 4);
           tl[j] = tok < N ? t : __builtin_inff();
+          const uint32_t vm = (__float_as_uint(tl[j]) + 0x8000u) >> 16;
+          t16[j] = (int)((vm < 1u ? 1u : vm) << 16);
         }
         // first entry of the (token j = 0, list) list, in entries; token j adds j * lstride (host checks 32 bits)
         const uint32_t lbase0 = (uint32_t)(((tok0 + wn * 128 + r32) * p.nL + list) * FUSED_SLOTS);
         const uint32_t lstride = 32u * (uint32_t)p.nL * FUSED_SLOTS;
-        uint32_t* q = reinterpret_cast<uint32_t*>(lds + NSTAGE * STAGE_BYTES) + wave * (QLANE * 64);
+        uint2* q = reinterpret_cast<uint2*>(lds + NSTAGE * STAGE_BYTES) + wave * (QLANE * 64);
         // byte cursor into this lane's queue: entry e of lane l sits at q[e * 64 + l]; a full queue keeps overwriting
         // its last slot while the cursor runs on and reports the overflow
-        char* const qb = reinterpret_cast<char*>(q) + lane * 4;
-        uint32_t qoff = 0;  // bytes: 256 per entry
-        constexpr uint32_t QLAST = (QLANE - 1) * 256;
+        char* const qb = reinterpret_cast<char*>(q) + lane * 8;
+        uint32_t qoff = 0;  // bytes: 512 per entry
+        uint32_t gm[2] = {0u, 0u};  // bit (i * 4 + g) * 4 + j: this lane had a hit in that group
+        constexpr uint32_t QLAST = (QLANE - 1) * 512;
         if (!(dbg & 2))
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -373,18 +383,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
                 // negative integer); integer max needs no NaN canonicalisation: v_max3_i32 + v_max_i32 + one compare
                 const int mx = max(max(__float_as_int(a[0]), __float_as_int(a[1])),
                                    max(__float_as_int(a[2]), __float_as_int(a[3])));
-                if (__ballot(mx >= __float_as_int(tl[j])) != 0ull) {
-#pragma unroll
-                  for (int qq = 0; qq < 4; ++qq) {
-                    // Straight-line, no EXEC change and no branch per element: EVERY lane writes its entry at its
-                    // cursor, only lanes with a hit advance the cursor (a miss is overwritten by the next write).
-                    // entry = bf16(a) << 16 | 0x3f00 | code: the low half is the bf16 of a constant float whose bf16
-                    // bits are 0x3f00 | code (a normal number in [0.5, 2): exact), so one packed convert builds it.
-                    const uint32_t code = (uint32_t)(j * 64 + i * 16 + g * 4 + qq);
-                    const bf16x2_t pk = {(__bf16)__uint_as_float((0x3f00u | code) << 16), (__bf16)a[qq]};
-                    *reinterpret_cast<uint32_t*>(qb + (qoff < QLAST ? qoff : QLAST)) = __builtin_bit_cast(uint32_t, pk);
-                    qoff += a[qq] >= tl[j] ? 256u : 0u;
-                  }
+                const bool hit = mx >= __float_as_int(tl[j]);
+                if (__ballot(hit) != 0ull) {
+                  const int gi = (i * 4 + g) * 4 + j;
+                  const bf16x2_t p01 = {(__bf16)a[0], (__bf16)a[1]}, p23 = {(__bf16)a[2], (__bf16)a[3]};  // 2 x v_cvt_pk
+                  *reinterpret_cast<uint2*>(qb + (qoff < QLAST ? qoff : QLAST)) =
+                      make_uint2(__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23));
+                  qoff += hit ? 512u : 0u;
+                  gm[gi >> 5] |= hit ? (1u << (gi & 31)) : 0u;
                 }
               }
             }
@@ -392,18 +398,30 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
           }
         }
         // ---- queue -> lists (rolled: one copy of this code per kernel)
-        int nq = (int)(qoff >> 8);
+        int nq = (int)(qoff >> 9);
         const bool q_over = nq > QLANE - 1;  // (slot QLANE - 1 is where writes go once the queue is full: not an entry)
         nq = q_over ? QLANE - 1 : nq;
         uint32_t cntp = 0;  // the four list lengths of this lane, one byte each
 #pragma unroll 1
         for (int e = 0; __ballot(e < nq) != 0ull; ++e) {
           if (e < nq) {
-            const uint32_t ent = q[e * 64 + lane];
-            const uint32_t j = (ent >> 6) & 3u, sh = j * 8u;  // (bits 8..15 hold the 0x3f of the packed convert)
-            const uint32_t c = (cntp >> sh) & 255u;
-            if (c < (uint32_t)FUSED_SLOTS && !(dbg & 1)) p.lists[lbase0 + j * lstride + c] = (ent & 0xffff0000u) | (ent & 63u);
-            cntp += 1u << sh;
+            const uint2 ent = q[e * 64 + lane];
+            const int gi = gm[0] != 0u ? __builtin_ctz(gm[0]) : 32 + __builtin_ctz(gm[1]);  // this entry's group
+            if (gm[0] != 0u) gm[0] &= gm[0] - 1u;
+            else gm[1] &= gm[1] - 1u;
+            const uint32_t j = (uint32_t)gi & 3u, sh = j * 8u, pos0 = ((uint32_t)gi >> 2) * 4u;
+            const int thr = j == 0 ? t16[0] : j == 1 ? t16[1] : j == 2 ? t16[2] : t16[3];
+            const uint32_t lb = lbase0 + j * lstride;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const uint32_t w = qq < 2 ? ent.x : ent.y;
+              const uint32_t vb = (qq & 1) ? (w & 0xffff0000u) : (w << 16);  // bf16 bits << 16
+              if ((int)vb >= thr) {
+                const uint32_t c = (cntp >> sh) & 255u;
+                if (c < (uint32_t)FUSED_SLOTS && !(dbg & 1)) p.lists[lb + c] = vb | (pos0 + (uint32_t)qq);
+                cntp += 1u << sh;
+              }
+            }
           }
         }
 #pragma unroll
