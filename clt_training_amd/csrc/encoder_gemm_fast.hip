@@ -374,23 +374,36 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             if (i * 32 + 8 * g < lat_left) {
+              // the four token groups of this (i, g) together: 16 reads, 8 max, 4 compares into SGPR pairs, THEN the four
+              // wave-uniform branches -- one VALU -> SALU dependency stall per four groups instead of one per group
+              float a[4][4];
+              unsigned long long hm[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                float a[4];
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) a[qq] = acc_read(acc[i][j][4 * g + qq]);
+                for (int qq = 0; qq < 4; ++qq) a[j][qq] = acc_read(acc[i][j][4 * g + qq]);
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
                 // thresholds are positive, so a >= t  <=>  bits(a) >= bits(t) as SIGNED integers (a negative float is a
                 // negative integer); integer max needs no NaN canonicalisation: v_max3_i32 + v_max_i32 + one compare
-                const int mx = max(max(__float_as_int(a[0]), __float_as_int(a[1])),
-                                   max(__float_as_int(a[2]), __float_as_int(a[3])));
-                const bool hit = mx >= __float_as_int(tl[j]);
-                if (__ballot(hit) != 0ull) {
+                const int mx = max(max(__float_as_int(a[j][0]), __float_as_int(a[j][1])),
+                                   max(__float_as_int(a[j][2]), __float_as_int(a[j][3])));
+                hm[j] = __ballot(mx >= __float_as_int(tl[j]));
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) asm volatile("" : "+s"(hm[j]));  // all four masks exist before the first branch
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (hm[j] != 0ull) {
+                  uint32_t flag;  // 1 in the lanes with a hit (the mask is already an SGPR pair: one v_cndmask)
+                  asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(flag) : "s"(hm[j]));
                   const int gi = (i * 4 + g) * 4 + j;
-                  const bf16x2_t p01 = {(__bf16)a[0], (__bf16)a[1]}, p23 = {(__bf16)a[2], (__bf16)a[3]};  // 2 x v_cvt_pk
+                  const bf16x2_t p01 = {(__bf16)a[j][0], (__bf16)a[j][1]}, p23 = {(__bf16)a[j][2], (__bf16)a[j][3]};  // 2 x v_cvt_pk
                   *reinterpret_cast<uint2*>(qb + (qoff < QLAST ? qoff : QLAST)) =
                       make_uint2(__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23));
-                  qoff += hit ? 512u : 0u;
-                  gm[gi >> 5] |= hit ? (1u << (gi & 31)) : 0u;
+                  qoff += flag << 9;               // v_lshl_add_u32
+                  gm[gi >> 5] |= flag << (gi & 31);  // v_lshl_or_b32
                 }
               }
             }
