@@ -48,6 +48,7 @@ class KernelProfile:
     def __init__(self, names=None):
         self.names = None if names is None else set(names)
         self.records = {}
+        self.active = True  # bench.py switches it per step: every event pair costs ~10 us of idle GPU at a call boundary
 
     def add(self, name, start, end):
         self.records.setdefault(name, []).append((start, end))
@@ -67,7 +68,7 @@ PROFILE: Optional[KernelProfile] = None
 def _call(name: str, *args):
     fn = getattr(_lib.load(), name)
     prof = PROFILE
-    if prof is not None and (prof.names is None or name in prof.names):
+    if prof is not None and prof.active and (prof.names is None or name in prof.names):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = fn(*args)

@@ -736,3 +736,30 @@ def test_encode_batchtopk_vs_reference_golden(ops):
         torch.testing.assert_close(W.grad.cpu(), t[f"gW_{tag}"], **FP32)
         torch.testing.assert_close(b.grad.cpu(), t[f"gb_{tag}"], **FP32)
         torch.testing.assert_close(x.grad.cpu(), t[f"gx_{tag}"], **FP32)
+
+
+@pytest.mark.parametrize("N,k,M,lo,hi", [
+    (1, 1, 1, 0, 1),                    # one entry, one latent, one 1-bit pass
+    (3, 5, 64, 0, 64),                  # fewer entries than a round
+    (300, 7, 300_001, 0, 300_001),      # 19-bit keys: three passes
+    (5000, 16, 70_000, 30_000, 50_000), # a latent shard: foreign entries are dropped by the first pass
+    (257, 33, (1 << 20) + 3, 1 << 19, (1 << 20) + 3),  # 20-bit local keys, shard at the top of the range
+    (2048, 8, 40, 0, 40),               # every segment long (410 entries per latent on average), 6-bit keys
+    (700, 4, 1000, 990, 1000),          # almost nothing owned
+])
+def test_segments_radix_sort_shapes(ops, N, k, M, lo, hi):
+    """clt_segments_build's own radix sort (csrc/segments.hip) against a stable torch sort: pass counts 1-3, ragged
+    last blocks, shards, empty and long segments.  Bit-exact: perm (owned prefix), offsets, owned count."""
+    g = torch.Generator().manual_seed(N * 31 + k)
+    idx = torch.randint(0, M, (N, k), generator=g)
+    seg = ops.segments_build(idx.to(DEV), hi - lo, lat_begin=lo)
+    flat = idx.flatten()
+    owned = (flat >= lo) & (flat < hi)
+    ids = torch.nonzero(owned).flatten()
+    keys = flat[ids] - lo
+    order = torch.sort(keys, stable=True).indices
+    want_perm = ids[order]
+    want_off = torch.zeros(hi - lo + 1, dtype=torch.long)
+    want_off[1:] = torch.cumsum(torch.bincount(keys, minlength=hi - lo), 0)
+    assert torch.equal(seg.offsets.cpu().long(), want_off)
+    assert torch.equal(seg.perm.cpu().long()[: ids.numel()], want_perm)
