@@ -168,7 +168,7 @@ int clt_decode_bwd_acts_multi(const clt_decode_source* h_sources, int n_sources,
  *   segment of local row r, offsets[M] = number of entries this shard owns, offsets[M+1] = 1 if some segment
  *   holds more than 512 entries (read by the long-row helper of clt_spt_dense_adam / clt_decode_bwd_rows_adam).
  * Sharded: only entries with idx in [lat_begin, lat_begin + M) form segments (local row = idx - lat_begin);
- * the others are sorted behind offsets[M].                                            */
+ * the others are dropped by the first sorting pass: perm[offsets[M] ...] is unspecified.                 */
 size_t clt_segments_workspace_bytes(int64_t n_entries, int64_t M);
 int clt_segments_build(const int64_t* idx, int64_t n_entries, int64_t M, int64_t lat_begin, int32_t* perm,
                        int32_t* offsets, void* workspace, size_t workspace_bytes, clt_stream_t stream);
