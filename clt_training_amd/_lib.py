@@ -42,6 +42,8 @@ SIGNATURES = {
     "clt_last_error": (C.c_char_p, []),
     "clt_encoder_gemm_relu": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _i32, _vp]),
     "clt_topk_rows": (_i32, [_vp, _i32, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "clt_candidates_pack": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp]),
+    "clt_candidates_unpack": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp]),
     "clt_groupmax_rows": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
     "clt_encode_groupmax_fwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "clt_encode_topk_workspace_bytes": (_sz, [_i64, _i64, _i32]),

@@ -340,11 +340,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
         //      branch (9 instructions; ~63 % of the groups have no hit in any lane).  A group with a hit runs a short
         //      INLINE straight-line body (10 instructions, no EXEC change, no branch per element): EVERY lane writes
         //      the group's four values, rounded to bf16, as ONE 8-byte entry at its lane-private LDS queue cursor; only
-        //      lanes with a hit advance the cursor and set the group's bit in a 64-bit per-lane mask (a miss is
-        //      overwritten by the next write).  The e-th queue entry of a lane belongs to the e-th set bit of its mask,
-        //      so the entry needs no code.  ONE rolled loop at the end of the tile turns queue entries into list
-        //      entries, testing each of the four values against the threshold's bf16 value (bf16(a) >= v_m is the fp32
-        //      test a >= tau up to the rounding interval's lower edge, which only ever ADDED candidates).
+        //      lanes with a hit advance the cursor and set the group's bit in a per-lane mask (a miss is overwritten by
+        //      the next write).  The e-th queue entry of a lane belongs to the e-th set bit of its mask, so the entry
+        //      needs no code.  A rolled loop after each QUARTER of the tile turns queue entries into list entries,
+        //      testing each of the four values against the threshold's bf16 value (bf16(a) >= v_m is the fp32 test
+        //      a >= tau up to the rounding interval's lower edge, which only ever ADDED candidates).
         //      (History: 64 unrolled out-of-line handlers, ~100 KB of code and an instruction-cache miss per hit group;
         //      then per-element 4-byte entries with a code, ~33 instructions per hit group.)
         const int list = (cur_lt * 2 + wm) * 2 + h;
@@ -365,12 +365,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
         // byte cursor into this lane's queue: entry e of lane l sits at q[e * 64 + l]; a full queue keeps overwriting
         // its last slot while the cursor runs on and reports the overflow
         char* const qb = reinterpret_cast<char*>(q) + lane * 8;
-        uint32_t qoff = 0;  // bytes: 512 per entry
-        uint32_t gm[2] = {0u, 0u};  // bit (i * 4 + g) * 4 + j: this lane had a hit in that group
         constexpr uint32_t QLAST = (QLANE - 1) * 512;
+        uint32_t cntp = 0;  // the four list lengths of this lane, one byte each
+        bool q_over = false;
+        uint32_t qoff = 0;           // bytes: 512 per entry
+        uint32_t gm[2] = {0u, 0u};   // bit (i * 4 + g) * 4 + j: this lane had a hit in that group
+        const bool qflush = p.qflush != 0;  // wave-uniform (host: fused_plan)
         if (!(dbg & 2))
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          // Scan a quarter of the tile (32 latents x 128 tokens per wave) into the queue; the queue is turned into list
+          // entries after the last quarter or -- when the host expects more than the queue's QLANE - 1 = 9 hit groups per
+          // lane and tile to be likely (latent shards: ~2.3 per tile against ~0.5 unsharded) -- after every quarter.
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             if (i * 32 + 8 * g < lat_left) {
@@ -398,44 +404,46 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
                 if (hm[j] != 0ull) {
                   uint32_t flag;  // 1 in the lanes with a hit (the mask is already an SGPR pair: one v_cndmask)
                   asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(flag) : "s"(hm[j]));
-                  const int gi = (i * 4 + g) * 4 + j;
                   const bf16x2_t p01 = {(__bf16)a[j][0], (__bf16)a[j][1]}, p23 = {(__bf16)a[j][2], (__bf16)a[j][3]};  // 2 x v_cvt_pk
                   *reinterpret_cast<uint2*>(qb + (qoff < QLAST ? qoff : QLAST)) =
                       make_uint2(__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23));
-                  qoff += flag << 9;               // v_lshl_add_u32
-                  gm[gi >> 5] |= flag << (gi & 31);  // v_lshl_or_b32
+                  qoff += flag << 9;                                              // v_lshl_add_u32
+                  gm[((i * 4 + g) * 4 + j) >> 5] |= flag << (((i * 4 + g) * 4 + j) & 31);  // v_lshl_or_b32
                 }
               }
             }
             CLT_FENCE();
           }
-        }
-        // ---- queue -> lists (rolled: one copy of this code per kernel)
-        int nq = (int)(qoff >> 9);
-        const bool q_over = nq > QLANE - 1;  // (slot QLANE - 1 is where writes go once the queue is full: not an entry)
-        nq = q_over ? QLANE - 1 : nq;
-        uint32_t cntp = 0;  // the four list lengths of this lane, one byte each
+          if (!qflush && i < 3) continue;
+          // ---- queue -> lists (rolled)
+          int nq = (int)(qoff >> 9);
+          q_over = q_over || nq > QLANE - 1;  // (slot QLANE - 1 is where writes go once the queue is full: not an entry)
+          nq = nq > QLANE - 1 ? QLANE - 1 : nq;
 #pragma unroll 1
-        for (int e = 0; __ballot(e < nq) != 0ull; ++e) {
-          if (e < nq) {
-            const uint2 ent = q[e * 64 + lane];
-            const int gi = gm[0] != 0u ? __builtin_ctz(gm[0]) : 32 + __builtin_ctz(gm[1]);  // this entry's group
-            if (gm[0] != 0u) gm[0] &= gm[0] - 1u;
-            else gm[1] &= gm[1] - 1u;
-            const uint32_t j = (uint32_t)gi & 3u, sh = j * 8u, pos0 = ((uint32_t)gi >> 2) * 4u;
-            const int thr = j == 0 ? t16[0] : j == 1 ? t16[1] : j == 2 ? t16[2] : t16[3];
-            const uint32_t lb = lbase0 + j * lstride;
+          for (int e = 0; __ballot(e < nq) != 0ull; ++e) {
+            if (e < nq) {
+              const uint2 ent = q[e * 64 + lane];
+              const int gi = gm[0] != 0u ? __builtin_ctz(gm[0]) : 32 + __builtin_ctz(gm[1]);  // the e-th set bit
+              if (gm[0] != 0u) gm[0] &= gm[0] - 1u;
+              else gm[1] &= gm[1] - 1u;
+              const uint32_t j = (uint32_t)gi & 3u, sh = j * 8u, pos0 = ((uint32_t)gi >> 2) * 4u;
+              const int thr = j == 0 ? t16[0] : j == 1 ? t16[1] : j == 2 ? t16[2] : t16[3];
+              const uint32_t lb = lbase0 + j * lstride;
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-              const uint32_t w = qq < 2 ? ent.x : ent.y;
-              const uint32_t vb = (qq & 1) ? (w & 0xffff0000u) : (w << 16);  // bf16 bits << 16
-              if ((int)vb >= thr) {
-                const uint32_t c = (cntp >> sh) & 255u;
-                if (c < (uint32_t)FUSED_SLOTS && !(dbg & 1)) p.lists[lb + c] = vb | (pos0 + (uint32_t)qq);
-                cntp += 1u << sh;
+              for (int qq = 0; qq < 4; ++qq) {
+                const uint32_t w = qq < 2 ? ent.x : ent.y;
+                const uint32_t vb = (qq & 1) ? (w & 0xffff0000u) : (w << 16);  // bf16 bits << 16
+                if ((int)vb >= thr) {
+                  const uint32_t c = (cntp >> sh) & 255u;
+                  if (c < (uint32_t)FUSED_SLOTS && !(dbg & 1)) p.lists[lb + c] = vb | (pos0 + (uint32_t)qq);
+                  cntp += 1u << sh;
+                }
               }
             }
           }
+          qoff = 0;
+          gm[0] = gm[1] = 0u;
+          CLT_FENCE();
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -617,6 +625,9 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
       break;
     }
   }
+  // hit groups per lane and tile of the filter pass: 4 lists x 64 latents x (m S / M) candidates per latent.  The queue
+  // holds 9 per lane between flushes; P(Poisson(0.6) >= 10) ~ 1e-9 per lane and tile
+  pl.qflush = 256.0 * pl.m * (double)S / (double)M > 0.6 ? 1 : 0;
   pl.nltA = (int)nltA;
   pl.nltB = (int)nltB;
   pl.ntt = (int)ntt;
@@ -677,6 +688,7 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   pb.lists = (uint32_t*)(ws + pl.off_lists);
   pb.counts = (uint8_t*)(ws + pl.off_counts);
   pb.nL = pl.nL;
+  pb.qflush = pl.qflush;
   rc = launch_gemm_fast(pb, CLT_BF16, true, cus, st);
   if (rc != CLT_OK) return rc;
   // merge

@@ -49,6 +49,7 @@ struct FastArgs {
   uint32_t* lists;
   uint8_t* counts;
   int nL;
+  int qflush;         // filter mode: turn the hit queue into list entries after every quarter tile, not once per tile
   const int* gate;    // if set, the kernel returns at once unless *gate != 0 ...
   const int* tt_map;  // ... and, if tt_map is set too, *gate is the number of token tiles to do and tt_map[i] their ids
   int dbg;
@@ -72,6 +73,7 @@ struct FusedPlan {
   bool ok;
   int S, nltA, nltB, ntt, nL;
   int m;            // rank of the sample value that serves as threshold (<= k)
+  int qflush;       // see FastArgs
   int64_t lds, Ls;  // sample matrix: leading dimension and valid columns
   size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, bytes;
 };

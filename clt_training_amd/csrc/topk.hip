@@ -235,6 +235,58 @@ __global__ __launch_bounds__(256) void groupmax_rows_kernel(const VT* __restrict
 
 }  // namespace clt
 
+namespace clt {
+__global__ void candidates_pack_kernel(const void* __restrict__ vals, int val_dtype, const int64_t* __restrict__ idx,
+                                       int64_t idx_offset, int64_t n, int64_t* __restrict__ packed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t vb = __float_as_uint(load_scalar(vals, val_dtype, i));
+  packed[i] = (int64_t)((vb << 32) | (uint64_t)(uint32_t)(idx[i] + idx_offset));
+}
+
+template <typename VT>
+__global__ void candidates_unpack_kernel(const int64_t* __restrict__ packed, int64_t groups, int64_t rows, int64_t k,
+                                         VT* __restrict__ vals, int64_t* __restrict__ idx) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // output position: (t, r, j)
+  const int64_t gk = groups * k;
+  if (o >= rows * gk) return;
+  const int64_t t = o / gk, rj = o - t * gk, r = rj / k, j = rj - r * k;
+  const uint64_t p = (uint64_t)packed[(r * rows + t) * k + j];
+  const float v = __uint_as_float((uint32_t)(p >> 32));
+  if constexpr (sizeof(VT) == 2) vals[o] = (VT)v;
+  else vals[o] = v;
+  idx[o] = (int64_t)(p & 0xffffffffull);
+}
+}  // namespace clt
+
+extern "C" int clt_candidates_pack(const void* vals, int val_dtype, const int64_t* idx, int64_t idx_offset, int64_t n,
+                                   int64_t* packed, clt_stream_t stream) {
+  CLT_CHECK_ARG(vals && idx && packed, "clt_candidates_pack: null pointer");
+  CLT_CHECK_ARG(valid_dtype(val_dtype) && n > 0 && n < (1ll << 40) && idx_offset >= 0 && idx_offset < (1ll << 32),
+                "clt_candidates_pack: bad arguments");
+  hipLaunchKernelGGL(candidates_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vals,
+                     val_dtype, idx, idx_offset, n, packed);
+  CLT_CHECK_LAUNCH("clt_candidates_pack");
+  return CLT_OK;
+}
+
+extern "C" int clt_candidates_unpack(const int64_t* packed, int64_t groups, int64_t rows, int64_t k, void* vals,
+                                     int val_dtype, int64_t* idx, clt_stream_t stream) {
+  CLT_CHECK_ARG(packed && vals && idx, "clt_candidates_unpack: null pointer");
+  CLT_CHECK_ARG(valid_dtype(val_dtype) && groups > 0 && rows > 0 && k > 0 && groups * rows * k < (1ll << 40),
+                "clt_candidates_unpack: bad arguments");
+  const int64_t n = groups * rows * k;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (val_dtype == CLT_BF16)
+    hipLaunchKernelGGL((candidates_unpack_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, packed, groups, rows, k,
+                       (bf16_t*)vals, idx);
+  else
+    hipLaunchKernelGGL((candidates_unpack_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, packed, groups, rows, k,
+                       (float*)vals, idx);
+  CLT_CHECK_LAUNCH("clt_candidates_unpack");
+  return CLT_OK;
+}
+
 extern "C" int clt_groupmax_rows(const void* vals, int val_dtype, int64_t ld, int64_t N, int64_t M, int k,
                                  void* out_vals, int out_dtype, int64_t* out_idx, clt_stream_t stream) {
   using namespace clt;

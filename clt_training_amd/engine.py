@@ -416,7 +416,7 @@ class CLTEngine:
                 b.data[:] = b.data * (d**0.5 / out_norm)
             lp.b_enc.data[:] = (lp.b_enc.data.float() * (d**0.5 / in_norm)).to(lp.b_enc.dtype)
 
-    def _merge_candidates(self, v: Tensor, gidx: Tensor, k: int):
+    def _merge_candidates(self, v: Tensor, idx: Tensor, k: int, lat_begin: int = 0):
         """The TP top-k merge of fused_encoder.py:347-360 without replicating it: the reference all-gathers the k local
         candidates of every shard to every rank and each rank runs the second top-k over ALL tokens.  Here rank r merges
         only its own N / tp tokens: one all-to-all brings it the tp * k candidates of those tokens (value bits and global
@@ -428,8 +428,15 @@ class CLTEngine:
         N = v.shape[0]
         assert N % tp == 0
         vdt = v.dtype
-        packed = (v.float().view(torch.int32).to(torch.int64) << 32) | gidx  # post-ReLU values: sign bit clear
-        mine = comm.all_to_all_rows(packed)                                   # [tp * N/tp, k]: block r' from rank r'
+        if hasattr(ops, "candidates_pack"):  # two small kernels either side of each collective (clt_candidates_*)
+            mine = comm.all_to_all_rows(ops.candidates_pack(v, idx, lat_begin))  # [tp * N/tp, k]: block r' from rank r'
+            cand_v, cand_i = ops.candidates_unpack(mine, tp, k, vdt)         # [N/tp, tp * k], rank by rank
+            mv, mi = ops.topk_rows(cand_v, k, cand_idx=cand_i)
+            win = comm.all_gather_rows(ops.candidates_pack(mv, mi))          # [N, k]
+            return ops.candidates_unpack(win, 1, k, vdt)
+        # (the oracle-backed ops double of the CPU tests: the same format in torch ops)
+        packed = (v.float().view(torch.int32).to(torch.int64) << 32) | (idx + lat_begin)  # post-ReLU: sign bit clear
+        mine = comm.all_to_all_rows(packed)
         n = N // tp
         cand = mine.view(tp, n, k).permute(1, 0, 2).reshape(n, tp * k)
         cand_v = (cand >> 32).to(torch.int32).view(torch.float32).to(vdt)
@@ -471,7 +478,7 @@ class CLTEngine:
             kk = 4 * k if cfg.activation == "batchtopk" else k  # fused_encoder.py:315-318: row top-4k first
             v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, kk, out_dtype=cd)
             if comm.world > 1:
-                v, idx = self._merge_candidates(v, idx + lp.lat_begin, kk)
+                v, idx = self._merge_candidates(v, idx, kk, lp.lat_begin)
             if cfg.activation == "batchtopk":
                 # the batch-wide threshold of fused_encoder.py:204-240 on the MERGED rows (the single-device rule; every
                 # rank holds the same [N, 4k] and takes the same threshold)

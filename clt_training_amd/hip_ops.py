@@ -95,6 +95,29 @@ def workspace(device, nbytes: int, tag: str = "default") -> Tensor:
     return buf
 
 
+# ----------------------------------------------------------------------------- TP candidate exchange format
+def candidates_pack(vals: Tensor, idx: Tensor, idx_offset: int = 0) -> Tensor:
+    """[..] values (>= 0) and int64 indices -> int64 (float32 bits of the value << 32 | idx + idx_offset): one tensor,
+    one collective (engine.CLTEngine._merge_candidates)."""
+    vals, idx = _c(vals), _idx(idx)
+    assert vals.shape == idx.shape
+    out = torch.empty(vals.shape, dtype=torch.int64, device=vals.device)
+    _call("clt_candidates_pack", _ptr(vals), _dt(vals), _ptr(idx), int(idx_offset), vals.numel(), _ptr(out), _stream(vals))
+    return out
+
+
+def candidates_unpack(packed: Tensor, groups: int, k: int, dtype) -> tuple:
+    """packed [groups * rows, k] as an all-to-all delivers it (block r = what rank r sent) -> values [rows, groups * k]
+    in ``dtype`` and int64 indices, row t holding token t's candidates rank by rank."""
+    packed = _c(packed)
+    assert packed.dtype == torch.int64 and packed.shape[-1] == k and packed.numel() % (groups * k) == 0
+    rows = packed.numel() // (groups * k)
+    vals = torch.empty(rows, groups * k, dtype=dtype, device=packed.device)
+    idx = torch.empty(rows, groups * k, dtype=torch.int64, device=packed.device)
+    _call("clt_candidates_unpack", _ptr(packed), groups, rows, k, _ptr(vals), _dt(vals), _ptr(idx), _stream(packed))
+    return vals, idx
+
+
 # ----------------------------------------------------------------------------- encoder
 def encoder_gemm_relu(x: Tensor, W: Tensor, b: Optional[Tensor], out_dtype=None, out: Optional[Tensor] = None) -> Tensor:
     x, W = _c(x), _c(W)

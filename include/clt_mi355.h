@@ -68,6 +68,18 @@ int clt_topk_rows(const void* vals, int val_dtype, int64_t ld, const int64_t* ca
                   int64_t N, int64_t L, int k, void* out_vals, int out_dtype, int64_t* out_idx,
                   clt_stream_t stream);
 
+/* The exchange format of the TP top-k merge (fused_encoder.py:347-360 all-gathers values and int64 indices as two
+ * tensors; here one int64 per candidate carries both through ONE collective):
+ *   packed = (bits of float32(value) << 32) | (idx + idx_offset),  values >= 0, idx + idx_offset < 2^32.
+ * clt_candidates_pack:   vals [n] in `val_dtype`, idx [n] int64 -> packed [n] int64.
+ * clt_candidates_unpack: packed as the all-to-all delivers it, [groups][rows][k] (group r = what rank r sent), ->
+ *   vals / idx [rows][groups * k]: row t holds the candidates of token t from every rank, rank by rank (groups = 1:
+ *   a plain unpack).  vals in `val_dtype` (the value was widened exactly, so the narrowing is exact too).           */
+int clt_candidates_pack(const void* vals, int val_dtype, const int64_t* idx, int64_t idx_offset, int64_t n,
+                        int64_t* packed, clt_stream_t stream);
+int clt_candidates_unpack(const int64_t* packed, int64_t groups, int64_t rows, int64_t k, void* vals, int val_dtype,
+                          int64_t* idx, clt_stream_t stream);
+
 /* Encoder GEMM + bias + ReLU + row top-k in one call (whole of fused_encoder.py:310-322,372 for
  * activation="topk"); results are those of clt_encoder_gemm_relu -> clt_topk_rows bit for bit.
  * `workspace`: clt_encode_topk_workspace_bytes(N, M, out_dtype) bytes = room for the pre-activation matrix

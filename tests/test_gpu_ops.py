@@ -579,6 +579,24 @@ def test_fused_encode_topk_fallback_is_per_token_tile(ops):
     assert ops.encode_topk_fallback_tiles(x2, M)[0] == 0
 
 
+@pytest.mark.parametrize("N,M,d,k", [(2048, 12288, 768, 32),    # C2 at tp8: the shard of 98304 latents
+                                     (1024, 16384, 2048, 64),   # configs[2] (Llama-3.2-1B CLT) at tp8
+                                     (2048, 98304, 768, 32)])   # C2 unsharded
+def test_fused_encode_topk_stays_on_the_fused_path(ops, N, M, d, k):
+    """A guard on BEHAVIOUR, not results (those are exact either way): on an ordinary dictionary the fused path must not
+    send token tiles through the plain-GEMM fallback -- at latent-shard widths the candidate density per lane is ~5x the
+    unsharded one, and a hit queue sized for the unsharded shape overflowed on 4 of 5 token tiles there."""
+    g = torch.Generator(device=DEV).manual_seed(N + M)
+    x = torch.randn(N, d, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(M, d, device=DEV, generator=g) / d**0.5).to(torch.bfloat16)
+    b = 0.1 * torch.randn(M, device=DEV, generator=g)
+    v, i = ops.encode_topk(x, W, b, k)
+    flagged, tiles = ops.encode_topk_fallback_tiles(x, M)
+    assert tiles == (N + 255) // 256 and flagged == 0, (flagged, tiles)
+    v_ref, i_ref = _plain_encode_topk(ops, x, W, b, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+
+
 # --------------------------------------------------------------------------- FVU
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("masked", [False, True])
@@ -763,3 +781,24 @@ def test_segments_radix_sort_shapes(ops, N, k, M, lo, hi):
     want_off[1:] = torch.cumsum(torch.bincount(keys, minlength=hi - lo), 0)
     assert torch.equal(seg.offsets.cpu().long(), want_off)
     assert torch.equal(seg.perm.cpu().long()[: ids.numel()], want_perm)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_candidates_pack_unpack(ops, dtype):
+    """The exchange format of the TP top-k merge (clt_candidates_pack / _unpack) against its definition in torch ops,
+    including the [rank][token][k] -> [token][rank * k] regrouping of what an all-to-all delivers."""
+    g = torch.Generator().manual_seed(3)
+    tp, n, k = 4, 37, 5
+    v = torch.rand(tp * n, k, generator=g).to(dtype)
+    v[0, 0] = 0.0
+    idx = torch.randint(0, 1 << 20, (tp * n, k), generator=g)
+    off = 3 << 20
+    want = (v.float().view(torch.int32).to(torch.int64) << 32) | (idx + off)
+    got = ops.candidates_pack(v.to(DEV), idx.to(DEV), off)
+    assert torch.equal(got.cpu(), want)
+    cand = want.view(tp, n, k).permute(1, 0, 2).reshape(n, tp * k)
+    uv, ui = ops.candidates_unpack(got, tp, k, dtype)
+    assert uv.dtype == dtype and torch.equal(uv.cpu(), (cand >> 32).to(torch.int32).view(torch.float32).to(dtype))
+    assert torch.equal(ui.cpu(), cand & 0xFFFFFFFF)
+    pv, pi = ops.candidates_unpack(got, 1, k, dtype)
+    assert torch.equal(pv.cpu(), v) and torch.equal(pi.cpu(), idx + off)
