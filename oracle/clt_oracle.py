@@ -414,8 +414,9 @@ def clt_train_step(
     state = {}  # per live source: dict(xn, x_enc, v, idx, slot, gv_acc)
     fvus, accts, idxs, sae_outs = [], [], [], []
 
-    k_cfg = k
+    k_arg = k  # (k is re-bound per layer below)
     for j in range(L):
+        k_cfg = k_arg[j] if isinstance(k_arg, (list, tuple)) else k_arg  # TrainConfig.per_layer_k (trainer.py:364-368)
         lp = layers[j]
         d = xs[j].shape[-1]
         xn = _normalize_in(lp, xs[j].to(dt), normalize_io)
@@ -523,7 +524,7 @@ def clt_train_step(
                     grads[i][f"W_skips.{t}"] += Gi.T @ st["xn"]
                 tw = t if t < len(li.W_decs) else 0
                 gW = torch.zeros_like(grads[i][f"W_decs.{tw}"]).index_add_(
-                    0, st["idx"].reshape(-1), Gi.repeat_interleave(k, 0) * a.reshape(-1, 1))
+                    0, st["idx"].reshape(-1), Gi.repeat_interleave(st["idx"].shape[1], 0) * a.reshape(-1, 1))
                 ga = (li.W_decs[tw].to(dt)[st["idx"]] * Gi.unsqueeze(1)).sum(-1)
                 if ga2 is not None:
                     ga = ga + ga2[:, pos * k:(pos + 1) * k]
@@ -550,8 +551,9 @@ def clt_train_step(
                 st = state[i]
                 li = layers[i]
                 t = per_src[i]["t"]
-                ga = ga_cat[:, off : off + k]
-                off += k
+                ks = st["idx"].shape[1]  # (per_layer_k: the sources' bags differ in width)
+                ga = ga_cat[:, off : off + ks]
+                off += ks
                 scale = None if li.post_enc_scales is None else li.post_enc_scales[t].to(dt)
                 u, gp, gs = post_affine_bwd(st["v"], st["idx"], li.post_encs[t].to(dt), scale, ga)
                 grads[i][f"post_encs.{t}"] += gp
@@ -569,7 +571,7 @@ def clt_train_step(
                 # FusedEncoder.backward (fused_encoder.py:92-155) in fp64
                 gvm = st["gv"] * (st["v"] > 0).to(dt)
                 gW64 = torch.zeros_like(grads[i]["W_enc"]).index_add_(
-                    0, st["idx"].reshape(-1), st["x_enc"].repeat_interleave(k, 0) * gvm.reshape(-1, 1))
+                    0, st["idx"].reshape(-1), st["x_enc"].repeat_interleave(st["idx"].shape[1], 0) * gvm.reshape(-1, 1))
                 gb64 = torch.zeros_like(grads[i]["b_enc"]).index_add_(0, st["idx"].reshape(-1), gvm.reshape(-1))
                 grads[i]["W_enc"] += gW64
                 grads[i]["b_enc"] += gb64

@@ -88,9 +88,11 @@ def test_fvu_stages_equal_fused(ops, masked):
     torch.testing.assert_close(torch.cat([outs[0][1], outs[1][1]]), G, rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("case", ["clt", "sae", "concat"])
+@pytest.mark.parametrize("case", ["clt", "sae", "concat", "per_layer_k"])
 def test_engine_tp1_vs_oracle(case):
-    """The explicit engine on the HIP kernels (tp = 1), 3 train steps incl. step-0 init, Adam and schedule."""
+    """The explicit engine on the HIP kernels (tp = 1), 3 train steps incl. step-0 init, Adam and schedule.
+    ``per_layer_k`` (trainer.py:364-368, in force from the first optimizer step on): the live sources of a target carry
+    different k, so the one-launch fan-out does not apply and the step takes the per-source kernels."""
     import sys
     sys.path.insert(0, "tests")
     from test_tp_gloo import CASES, _make_problem, _oracle_layers
@@ -98,12 +100,14 @@ def test_engine_tp1_vs_oracle(case):
     from clt_training_amd.engine import ShardedCoder
     from clt_training_amd.tp import TPTrainer
 
-    sae_kw, L, cross = CASES[dict(clt="clt_skip_scale_norm_div", sae="sae", concat="clt_concat_scale_norm")[case]]
+    sae_kw, L, cross = CASES[dict(clt="clt_skip_scale_norm_div", sae="sae", concat="clt_concat_scale_norm",
+                                  per_layer_k="clt_skip_scale_norm_div")[case]]
+    pk = [3, 5, 4][:L] if case == "per_layer_k" else []
     d, N = 16, 24
     saes, steps = _make_problem(sae_kw, L, cross, d, N)
     hooks = [f"h.{i}" for i in range(L)]
     cfg = TrainConfig(sae=SparseCoderConfig(**sae_kw), hookpoints=hooks, cross_layer=cross, optimizer="adam", lr=1e-2,
-                      lr_warmup_steps=2)
+                      lr_warmup_steps=2, per_layer_k=list(pk))
     coders = [ShardedCoder.from_full(s, 0, 1, DEV) for s in saes]
     tr = TPTrainer(cfg, [None] * 4, device=DEV, input_widths={h: d for h in hooks}, coders=coders)
     layers = _oracle_layers(saes)
@@ -117,7 +121,8 @@ def test_engine_tp1_vs_oracle(case):
         batch = {h: (xs[l].to(DEV), ys[l].to(DEV)) for l, h in enumerate(hooks)}
         batch["loss_mask"] = m.to(DEV)
         got = tr.step(batch)
-        r = O.clt_train_step(layers, xs, ys, m, sae_kw["k"], normalize_io=sae_kw.get("normalize_io", False),
+        r = O.clt_train_step(layers, xs, ys, m, pk if pk and s > 0 else sae_kw["k"],
+                             normalize_io=sae_kw.get("normalize_io", False),
                              divide_cross_layer=sae_kw.get("divide_cross_layer", False),
                              coalesce=sae_kw.get("coalesce_topk", "none"))
         torch.testing.assert_close(torch.tensor([float(got[h]) for h in hooks]), torch.stack(r.fvus), rtol=2e-4, atol=1e-6)
