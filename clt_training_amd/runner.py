@@ -14,82 +14,98 @@ from torch import Tensor
 from .sparse_coder import MidDecoder, SparseCoder
 
 
-class CrossLayerRunner(object):
+class CrossLayerRunner:
+    """Keeps the live source layers (oldest first) and turns one hook call into the prediction of the current target.
+
+    The public surface is the reference's (``outputs``, ``to_restore``, ``encode``, ``decode``, ``__call__``,
+    ``restore``, ``reset``; runner.py:11-201); ``decode`` is organised as: bookkeeping over the live sources, then one of
+    three combiners -- ``_sum_of_sources`` ("none"), ``_second_read`` (``secondary_target_tied``), ``_one_bag``
+    ("concat" / "per-layer")."""
+
     def __init__(self):
-        self.outputs = {}
-        self.to_restore = {}
+        self.outputs = {}     # hookpoint -> MidDecoder of every source layer that still has targets to write
+        self.to_restore = {}  # hookpoint -> (MidDecoder, wrote its last target): deferred encoder backward
 
     def encode(self, x: Tensor, sparse_coder: SparseCoder, **kwargs):
         return sparse_coder(x=x, y=None, return_mid_decoder=True, **kwargs)
+
+    # ------------------------------------------------------------------ the three ways to combine the live sources
+    @staticmethod
+    def _sum_of_sources(cfg, mids, y, kwargs):
+        """runner.py:60-71: every earlier source decodes with its own W_decs[j - i] (no bias / skip extras of its own
+        target slot beyond the decoder's, no loss); the current layer adds their sum, scaled by 1 / divide_by."""
+        *earlier, current = mids
+        carried = 0
+        for mid in earlier:
+            carried = carried + mid(y, addition=0, no_extras=True, denormalize=False, **kwargs).sae_out
+        share = max(1, len(mids) - 1) if current.sparse_coder.cfg.divide_cross_layer else 1
+        return current(y, addition=carried / share, no_extras=cfg.secondary_target_tied,
+                       denormalize=not cfg.secondary_target_tied, **kwargs)
+
+    @staticmethod
+    def _second_read(current, bag, first, y, kwargs):
+        """runner.py:75-91: the current layer's slot-0 decoder reads every live candidate once more, on top of ``first``."""
+        again = current.copy(indices=bag[0], activations=bag[1])
+        return again(y, index=0, add_post_enc=False, no_extras=False, denormalize=True, addition=first.sae_out, **kwargs)
+
+    @staticmethod
+    def _one_bag(cfg, current, bag, n_live, y, kwargs):
+        """runner.py:93-158: ONE decode of the concatenated candidates through the target's single (tied) decoder."""
+        idx, val = bag
+        if cfg.topk_coalesced:  # :96-117: the k best of the [N, k * n_live] candidates (autograd routes the gradient back)
+            val, keep = torch.topk(val, k=cfg.k, dim=1)
+            idx = torch.gather(idx, 1, keep)
+        out = current.copy(indices=idx, activations=val)(y, index=0, add_post_enc=False, **kwargs)
+        if cfg.coalesce_topk == "per-layer":  # :130-158: report the current layer's own latents, 0 elsewhere
+            M = current.sparse_coder.num_latents
+            own_block = n_live - 1
+            out = replace(out, latent_indices=(out.latent_indices % M) * (out.latent_indices // M == own_block))
+        return out
 
     def decode(self, mid_out: MidDecoder, y: Tensor, module_name: str, detach_grad: bool = False,
                advance: bool = True, **kwargs):
         cfg = mid_out.sparse_coder.cfg
         if cfg.coalesce_topk == "group" or (cfg.secondary_target_tied and cfg.do_coalesce_topk):
             raise NotImplementedError("coalesce_topk in {'none', 'concat', 'per-layer'} is built")
-        self.outputs[module_name] = mid_out
+        self.outputs[module_name] = mid_out  # the newest entry: dicts keep insertion order
+        names, mids = list(self.outputs), list(self.outputs.values())
+        assert names[-1] == module_name
 
-        candidate_indices, candidate_values, layer_mids = [], [], []
-        output = 0
-        to_delete = set()
-        out, hookpoint = None, None
-        for i, (hookpoint, layer_mid) in enumerate(self.outputs.items()):
-            if detach_grad:
-                layer_mid.detach()
-            divide_by = max(1, len(self.outputs) - 1) if layer_mid.sparse_coder.cfg.divide_cross_layer else 1
-            layer_mids.append(layer_mid)
-            if cfg.do_coalesce_topk or cfg.secondary_target_tied:
-                # runner.py:52-54: candidates carry their position among the live sources.  "concat" takes it off
-                # again ((idx + i*M) % M == idx, :122); "per-layer" decodes with it: the target's W_dec holds one
-                # block of M rows per live source (sparse_coder.py:306-307)
-                off = i * layer_mid.sparse_coder.num_latents if cfg.coalesce_topk == "per-layer" else 0
-                candidate_indices.append(layer_mid.latent_indices + off if off else layer_mid.latent_indices)
-                candidate_values.append(layer_mid.current_latent_acts)
-            if detach_grad and advance:
-                self.to_restore[hookpoint] = (layer_mid, layer_mid.will_be_last)
-            if layer_mid.will_be_last:
-                to_delete.add(hookpoint)
-            if not cfg.do_coalesce_topk:
-                out = layer_mid(
-                    y,
-                    addition=(0 if hookpoint != module_name else (output / divide_by)),
-                    no_extras=(hookpoint != module_name) or cfg.secondary_target_tied,
-                    denormalize=(hookpoint == module_name) and not cfg.secondary_target_tied,
-                    **kwargs,
-                )
-                if hookpoint != module_name:
-                    output = output + out.sae_out
-            else:
-                layer_mid.next()
-
-        if cfg.secondary_target_tied:  # runner.py:75-91: the current layer's slot-0 decoder also reads every candidate
-            new_mid_out = mid_out.copy(indices=torch.cat(candidate_indices, dim=1),
-                                       activations=torch.cat(candidate_values, dim=1))
-            out = new_mid_out(y, index=0, add_post_enc=False, no_extras=False, denormalize=True, addition=out.sae_out,
-                              **kwargs)
-
-        if cfg.do_coalesce_topk:  # "concat" (runner.py:93-127)
-            best_indices = torch.cat(candidate_indices, dim=1)
-            best_values = torch.cat(candidate_values, dim=1)
-            if cfg.topk_coalesced:  # runner.py:96-117: the k best of the [N, k * n_live] candidates (a small torch op;
-                best_values, pos = torch.topk(best_values, k=cfg.k, dim=1)  # autograd routes the gradient back)
-                best_indices = torch.gather(best_indices, 1, pos)
-            new_mid_out = mid_out.copy(indices=best_indices, activations=best_values)
-            out = new_mid_out(y, index=0, add_post_enc=False, **kwargs)
-            if cfg.coalesce_topk == "concat":
+        # ---- bookkeeping, before any source moves on to its next target slot
+        if detach_grad:
+            for name, mid in zip(names, mids):
+                mid.detach()
                 if advance:
-                    del mid_out.x
-            else:  # "per-layer" (runner.py:130-158): report the current layer's own latents, 0 elsewhere
-                M = mid_out.sparse_coder.num_latents
-                out = replace(out, latent_indices=(out.latent_indices % M) * (out.latent_indices // M == i))
+                    self.to_restore[name] = (mid, mid.will_be_last)
+        done = [name for name, mid in zip(names, mids) if mid.will_be_last]
+        bag = None
+        if cfg.do_coalesce_topk or cfg.secondary_target_tied:
+            # runner.py:52-54: candidates carry their position among the live sources.  "concat" takes it off again
+            # ((idx + i*M) % M == idx, :122); "per-layer" decodes with it: the target's W_dec holds one block of M rows
+            # per live source (sparse_coder.py:306-307)
+            blocks = cfg.coalesce_topk == "per-layer"
+            bag = (torch.cat([mid.latent_indices + (pos * mid.sparse_coder.num_latents if blocks else 0)
+                              for pos, mid in enumerate(mids)], dim=1),
+                   torch.cat([mid.current_latent_acts for mid in mids], dim=1))
 
-        assert hookpoint == module_name  # last output guaranteed to be the current layer
-        if not advance:
-            for layer_mid in layer_mids:
-                layer_mid.prev()
+        # ---- the prediction
+        if cfg.do_coalesce_topk:
+            for mid in mids:
+                mid.next()
+            out = self._one_bag(cfg, mid_out, bag, len(mids), y, kwargs)
+            if cfg.coalesce_topk == "concat" and advance:
+                del mid_out.x
+        else:
+            out = self._sum_of_sources(cfg, mids, y, kwargs)
+            if cfg.secondary_target_tied:
+                out = self._second_read(mid_out, bag, out, y, kwargs)
+
         if advance:
-            for hookpoint in to_delete:
-                del self.outputs[hookpoint]
+            for name in done:
+                del self.outputs[name]
+        else:  # a dry run (e.g. an evaluation pass): every source stays on the slot it was on
+            for mid in mids:
+                mid.prev()
         return out
 
     def __call__(self, x: Tensor, y: Tensor, sparse_coder: SparseCoder, module_name: str, detach_grad: bool = False,
@@ -98,9 +114,10 @@ class CrossLayerRunner(object):
         return self.decode(mid_out, y, module_name, detach_grad, loss_mask=loss_mask, **decoder_kwargs)
 
     def restore(self):
-        for restorable, was_last in self.to_restore.values():
-            if was_last:
-                restorable.restore(True)
+        """The deferred encoder backward of the sources that wrote their last target in the hook call just finished."""
+        for mid, wrote_last in self.to_restore.values():
+            if wrote_last:
+                mid.restore(True)
         self.to_restore.clear()
 
     def reset(self):
