@@ -86,7 +86,9 @@ def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.
     pairs_per_target = mean number of live sources per target launch ((L + 1) / 2 with cross_layer = L)."""
     if name in ("clt_decode_fwd_multi", "clt_decode_bwd_acts_multi"):  # the pairs of one target: gathered rows + one row
         return es * N * (pairs_per_target * k / world + 1) * d, "byte"
-    if name == "clt_decode_bwd_rows_adam":  # parameter / exp_avg / exp_avg_sq rows read + written, G rows gathered
+    if name in ("clt_decode_bwd_rows_adam", "clt_decode_bwd_rows_adam_multi"):
+        # per (source, target) pair: parameter / exp_avg / exp_avg_sq rows read + written, G rows gathered; the batched
+        # entry point does `jobs` pairs per launch (the caller multiplies)
         return es * (6 * M * d + N * k / world * d), "byte"
     if name == "clt_decode_bwd_rows":
         return es * (2 * M * d + N * k / world * d), "byte"
@@ -304,8 +306,12 @@ def main():
         dominant, dom_ms = None, -1.0
         for name, (cnt, ms) in prof.summary().items():
             amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_adam, world, 1.0 if args.sae else (L + 1) / 2)
+            if amount is not None and name in prof.units:  # batched entry point: pairs per launch, counted live
+                amount *= prof.units[name] / cnt
             ent = {"launches_per_step": cnt / sampled, "mean_ms": round(ms, 4),
                    "ms_per_step": round(ms * cnt / sampled, 3)}
+            if name in prof.units:
+                ent["jobs_per_launch"] = round(prof.units[name] / cnt, 3)
             if amount is not None:
                 rate = amount / (ms * 1e-3)
                 peak = PEAK_BF16 if kind == "flop" else PEAK_HBM
@@ -323,7 +329,11 @@ def main():
             traffic = None
             pmcs = sorted((ROOT / "profiles").glob("r*_pmc_traffic*.json"))  # the newest pass (tools/pmc_traffic.py)
             if pmcs and world == 1 and (N, d, M, k, es) == (8192, 768, 98304, 32, 2):
-                traffic = json.loads(pmcs[-1].read_text())["kernels"].get(dominant, {}).get("hbm_bytes")
+                pk = json.loads(pmcs[-1].read_text())["kernels"]
+                traffic = pk.get(dominant, {}).get("hbm_bytes")
+                if dominant in prof.units:  # batched launch: PMC bytes per (source, target) pair x the pairs per launch
+                    per_job = pk.get(dominant, {}).get("hbm_bytes_per_job") or pk.get(dominant[:-len("_multi")], {}).get("hbm_bytes")
+                    traffic = None if per_job is None else int(per_job * prof.units[dominant] / prof.summary()[dominant][0])
             roofline = {"kernel": dominant, "bound": e["bound"], "achieved": e["achieved"],
                         "peak": 2500.0 if e["bound"] == "mfma" else 8000.0, "unit": e["unit"], "frac": e["frac"],
                         "traffic": traffic}

@@ -36,6 +36,16 @@ class DecodeSource(C.Structure):
 
 CLT_DECODE_MAX_SOURCES = 16
 
+
+class RowsJob(C.Structure):
+    """clt_rows_job (include/clt_mi355.h)."""
+
+    _fields_ = [("perm", _vp), ("offsets", _vp), ("acts", _vp), ("v", _vp), ("post_enc", _vp), ("post_scale", _vp),
+                ("W", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("grad_acts", _vp), ("g_post", _vp), ("g_scale", _vp)]
+
+
+CLT_ROWS_MAX_JOBS = 16
+
 # name -> (restype, argtypes); kept in the order of include/clt_mi355.h
 SIGNATURES = {
     "clt_version": (_i32, []),
@@ -64,6 +74,9 @@ SIGNATURES = {
                                    _vp, _vp, _i64, _vp, _sz, _vp]),
     "clt_decode_bwd_rows_adam": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
                                         _i32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _i64, _vp, _sz, _vp]),
+    "clt_rows_multi_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "clt_decode_bwd_rows_adam_multi": (_i32, [_vp, _i32, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32,
+                                              _i32, _i32, _i64, _vp, _sz, _vp]),
     "clt_rows_unit_norm": (_i32, [_vp, _i32, _i64, _i32, _f32, _vp]),
     "clt_rows_project_out": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp]),
     "clt_segment_sum": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

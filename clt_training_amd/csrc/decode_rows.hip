@@ -94,6 +94,58 @@ extern "C" int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offs
   return CLT_OK;
 }
 
+extern "C" size_t clt_rows_multi_workspace_bytes(int64_t n_entries, int d, int n_jobs) {
+  if (n_entries <= 0 || d <= 0 || n_jobs <= 0) return 256;
+  return (((rows_long_workspace_bytes(n_entries, d) + 255) & ~(size_t)255)) * (size_t)n_jobs + 512;
+}
+
+extern "C" int clt_decode_bwd_rows_adam_multi(const clt_rows_job* h_jobs, int n_jobs, int64_t M, int v_dtype,
+                                              const void* G, int g_dtype, int d, int k, int w_dtype, float lr, float b1,
+                                              float b2, float eps, int step, int project_out, int64_t n_entries,
+                                              void* workspace, size_t workspace_bytes, clt_stream_t stream) {
+  CLT_CHECK_ARG(h_jobs && n_jobs >= 1 && n_jobs <= CLT_ROWS_MAX_JOBS, "clt_decode_bwd_rows_adam_multi: 1..%d jobs",
+                CLT_ROWS_MAX_JOBS);
+  static_assert(CLT_ROWS_MAX_JOBS == ROWS_MAX_JOBS, "header and kernel disagree");
+  int ch = 0;
+  RowsJobs jobs = {};
+  for (int i = 0; i < n_jobs; ++i) {
+    const clt_rows_job& h = h_jobs[i];
+    const int rc = check_rows_args("clt_decode_bwd_rows_adam_multi", h.perm, h.offsets, M, h.acts, h.v, v_dtype,
+                                   h.post_scale, G, g_dtype, d, k, h.W, w_dtype, h.grad_acts, h.g_scale, &ch);
+    if (rc != CLT_OK) return rc;
+    CLT_CHECK_ARG(h.exp_avg && h.exp_avg_sq && aligned16(h.exp_avg) && aligned16(h.exp_avg_sq) && step >= 1,
+                  "clt_decode_bwd_rows_adam_multi: bad optimizer state");
+    RowsJob& jb = jobs.j[i];
+    jb.perm = h.perm;
+    jb.offsets = h.offsets;
+    jb.vals = h.acts;
+    jb.out = h.W;
+    jb.ad = make_adam_rows(h.exp_avg, h.exp_avg_sq, lr, b1, b2, eps, step, project_out != 0);
+    jb.bw = BwdActs{h.v, v_dtype, h.post_enc, h.post_scale, h.grad_acts, h.g_post, h.g_scale, nullptr};
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (!rows_lds_ok(d, dtype_size(w_dtype), ch)) {  // rows wider than the LDS-staged kernel takes: pair by pair
+    for (int i = 0; i < n_jobs; ++i) {
+      const clt_rows_job& h = h_jobs[i];
+      const int rc = clt_decode_bwd_rows_adam(h.perm, h.offsets, M, h.acts, h.v, v_dtype, h.post_enc, h.post_scale, G,
+                                              g_dtype, d, k, h.W, h.exp_avg, h.exp_avg_sq, w_dtype, h.grad_acts,
+                                              h.g_post, h.g_scale, lr, b1, b2, eps, step, project_out, n_entries,
+                                              workspace, workspace_bytes, stream);
+      if (rc != CLT_OK) return rc;
+    }
+    return CLT_OK;
+  }
+  const int rc = g_dtype == CLT_BF16
+                     ? launch_rows_lds_multi<bf16_t>(ch, st, jobs, n_jobs, M, G, d, k, n_entries, workspace, workspace_bytes)
+                     : launch_rows_lds_multi<float>(ch, st, jobs, n_jobs, M, G, d, k, n_entries, workspace, workspace_bytes);
+  if (rc != CLT_OK) {
+    set_error("clt_decode_bwd_rows_adam_multi: unsupported width");
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_decode_bwd_rows_adam_multi");
+  return CLT_OK;
+}
+
 // ---- SAE extras (sparse_coder.py:687-711; trainer.py:595-596, 793-795): row-wise passes over the decoder table, one wave
 //      per row, 16-byte chunks, fp32 arithmetic.  HBM-bound: one read + one write of the table (the reference's torch
 //      expressions make 3-6 passes).

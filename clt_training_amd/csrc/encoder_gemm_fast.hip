@@ -592,7 +592,8 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   // at ~1 expected entry (P(> 8) ~ 1e-6 per list): S up to M / (40 k).  Latent shards (M / tp rows) therefore still take
   // the fused path: M = 12288, k = 32 -> S = 9 (was 2); M = 16384, k = 64 -> S = 6 (was unfused).
   int64_t S = M / (40 * (int64_t)k);
-  if (S > 16) S = 16;
+  const int64_t s_cap = tuning_env("CLT_FUSED_SCAP", 16);  // -DCLT_TUNING builds only
+  if (S > s_cap) S = s_cap;
   if (S < 2) return pl;
   const int64_t nlt = (M + GEMM_TM - 1) / GEMM_TM, ntt = (N + GEMM_TN - 1) / GEMM_TN;
   const int64_t nltA = (nlt + S - 1) / S, nltB = nlt - nltA;

@@ -431,11 +431,11 @@ __device__ __forceinline__ int row_of_position(const int32_t* __restrict__ offse
 }
 
 template <typename T, int CH, int U, bool BWD>
-__global__ __launch_bounds__(64) void rows_long_kernel(const int32_t* __restrict__ perm,
-                                                       const int32_t* __restrict__ offsets, int64_t M,
-                                                       const float* __restrict__ vals, const void* __restrict__ gate,
-                                                       int gate_dtype, const T* __restrict__ dense, int d, int k,
-                                                       const T* __restrict__ W, const BwdActs bw, const LongRows lr) {
+__device__ __forceinline__ void rows_long_block(const int32_t* __restrict__ perm,
+                                                const int32_t* __restrict__ offsets, int64_t M,
+                                                const float* __restrict__ vals, const void* __restrict__ gate,
+                                                int gate_dtype, const T* __restrict__ dense, int d, int k,
+                                                const T* __restrict__ W, const BwdActs& bw, const LongRows& lr) {
   constexpr int E = Chunk<T>::E;
   const int lane = threadIdx.x;
   if (offsets[M + 1] == 0) return;  // clt_segments_build found no long segment: nothing to pre-reduce
@@ -548,13 +548,46 @@ __global__ __launch_bounds__(64) void rows_long_kernel(const int32_t* __restrict
   }
 }
 
+template <typename T, int CH, int U, bool BWD>
+__global__ __launch_bounds__(64) void rows_long_kernel(const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ offsets, int64_t M,
+                                                       const float* __restrict__ vals, const void* __restrict__ gate,
+                                                       int gate_dtype, const T* __restrict__ dense, int d, int k,
+                                                       const T* __restrict__ W, const BwdActs bw, const LongRows lr) {
+  rows_long_block<T, CH, U, BWD>(perm, offsets, M, vals, gate, gate_dtype, dense, d, k, W, bw, lr);
+}
+
+// Several row passes that share M, d, k and the dense rows (the decoder backward of every live source of ONE target:
+// the same loss gradient G, one table per source) as ONE launch: blockIdx.y names the job.  One ramp-up and one tail
+// instead of one per (source, target) pair, and one helper launch instead of one per pair.
+constexpr int ROWS_MAX_JOBS = 16;
+struct RowsJob {
+  const int32_t* perm;
+  const int32_t* offsets;
+  const float* vals;
+  void* out;  // ADAM: the parameter table
+  AdamRows ad;
+  BwdActs bw;
+  LongRows lr;
+};
+struct RowsJobs {
+  RowsJob j[ROWS_MAX_JOBS];
+};
+
+template <typename T, int CH, int U>
+__global__ __launch_bounds__(64) void rows_long_multi_kernel(const RowsJobs jobs, int64_t M, const T* __restrict__ dense,
+                                                             int d, int k) {
+  const RowsJob& jb = jobs.j[blockIdx.y];
+  rows_long_block<T, CH, U, true>(jb.perm, jb.offsets, M, jb.vals, nullptr, 0, dense, d, k, (const T*)jb.out, jb.bw, jb.lr);
+}
+
 // ADAM = false: the plain-gradient form (clt_spt_dense, clt_decode_bwd_rows): `out` receives the gradient row, only
 // the table row bw.W is staged (BWD) or nothing at all, and the long-segment pre-reduction is shared.
 template <typename T, int CH, int U, bool BWD, bool ADAM = true>
-__global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds_kernel(
+__device__ __forceinline__ void rows_lds_row(
     const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets, int64_t M, const float* __restrict__ vals,
     const void* __restrict__ gate, int gate_dtype, const T* __restrict__ dense, int d, int k, T* __restrict__ out,
-    float* __restrict__ rowsum, const AdamRows ad, const BwdActs bw, const LongRows lr) {
+    float* __restrict__ rowsum, const AdamRows& ad, const BwdActs& bw, const LongRows& lr) {
   constexpr int E = Chunk<T>::E;  // 16-byte chunks of the state rows and of the dense rows alike
   extern __shared__ __attribute__((aligned(16))) char rows_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -750,6 +783,22 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds
   }
 }
 
+template <typename T, int CH, int U, bool BWD, bool ADAM = true>
+__global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets, int64_t M, const float* __restrict__ vals,
+    const void* __restrict__ gate, int gate_dtype, const T* __restrict__ dense, int d, int k, T* __restrict__ out,
+    float* __restrict__ rowsum, const AdamRows ad, const BwdActs bw, const LongRows lr) {
+  rows_lds_row<T, CH, U, BWD, ADAM>(perm, offsets, M, vals, gate, gate_dtype, dense, d, k, out, rowsum, ad, bw, lr);
+}
+
+template <typename T, int CH, int U>
+__global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds_multi_kernel(
+    const RowsJobs jobs, int64_t M, const T* __restrict__ dense, int d, int k) {
+  const RowsJob& jb = jobs.j[blockIdx.y];
+  rows_lds_row<T, CH, U, true, true>(jb.perm, jb.offsets, M, jb.vals, nullptr, 0, dense, d, k, (T*)jb.out,
+                                                        nullptr, jb.ad, jb.bw, jb.lr);
+}
+
 // The LDS-staged kernel serves rows of up to 10 KiB (2 waves * 3 arrays * row <= 64 KiB of LDS) and 8 chunks per lane.
 static inline bool rows_lds_ok(int d, size_t elem, int ch, int narr = 3) {
   static const bool off = tuning_env("CLT_ROWS_LDS", 1) == 0;  // -DCLT_TUNING builds only: A/B against the register kernel
@@ -780,6 +829,38 @@ static int launch_rows_lds(int ch, hipStream_t st, const int32_t* perm, const in
     case 1: LAUNCH(1, 8); break;
     case 2: LAUNCH(2, 4); break;
     case 4: LAUNCH(4, 2); break;  // 3 waves per SIMD (<= 168 VGPRs) beat 4 gathers in flight at d = 2048
+    case 8: LAUNCH(8, 2); break;
+    default: return CLT_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH
+  return CLT_OK;
+}
+
+// n_jobs decoder-backward + Adam row passes in one launch (plus one helper launch for their long segments); job i's
+// long-row partials take the i-th slice of the workspace
+template <typename T>
+static int launch_rows_lds_multi(int ch, hipStream_t st, RowsJobs& jobs, int n_jobs, int64_t M, const void* dense, int d,
+                                 int k, int64_t n_entries, void* workspace, size_t workspace_bytes) {
+  const dim3 grid((unsigned)((M + 1) / 2), (unsigned)n_jobs);
+  const size_t lds = 2 * (size_t)3 * (size_t)d * sizeof(T);
+  const size_t per = (rows_long_workspace_bytes(n_entries, d) + 255) & ~(size_t)255;
+  const bool longs = workspace != nullptr && n_entries > ROWS_LT && workspace_bytes >= per * (size_t)n_jobs + 256;
+  const dim3 lgrid((unsigned)((n_entries + ROWS_LT - 1) / ROWS_LT), (unsigned)n_jobs);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  for (int i = 0; i < n_jobs; ++i) {
+    jobs.j[i].lr.partial = longs ? reinterpret_cast<float*>(base + per * (size_t)i) : nullptr;
+    jobs.j[i].lr.stride = d + 4;
+  }
+#define LAUNCH(CH, U)                                                                                              \
+  do {                                                                                                             \
+    if (longs)                                                                                                     \
+      hipLaunchKernelGGL((rows_long_multi_kernel<T, CH, U>), lgrid, dim3(64), 0, st, jobs, M, (const T*)dense, d, k); \
+    hipLaunchKernelGGL((rows_lds_multi_kernel<T, CH, U>), grid, dim3(128), lds, st, jobs, M, (const T*)dense, d, k); \
+  } while (0)
+  switch (ch) {
+    case 1: LAUNCH(1, 8); break;
+    case 2: LAUNCH(2, 4); break;
+    case 4: LAUNCH(4, 2); break;
     case 8: LAUNCH(8, 2); break;
     default: return CLT_ERR_UNSUPPORTED;
   }

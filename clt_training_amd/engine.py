@@ -52,6 +52,7 @@ class Routes:
     overlap_single: bool = False  # the same at world 1 (no collectives to hide; measured)
     graph: bool = True       # capture the step in a HIP graph where the trainer supports it
     pack: bool = True        # per-step packing of the skip matrices / decoder biases of all (source, target) pairs
+    rows_multi: bool = True  # the row passes of all live sources of a target in one launch (clt_decode_bwd_rows_adam_multi)
 
 
 ROUTES = Routes()
@@ -625,6 +626,11 @@ class CLTEngine:
                                  lat_begin=li.lat_begin, weight=sc_, grad_acts=st.gv,
                                  want_e_post=li.post_encs[t].requires_grad))
             bwd_multi = ops.decode_bwd_acts_multi(srcs, G)
+        # the row passes of all live sources in ONE launch when they share everything but their tables: same G (no
+        # 1/div), same table shape / dtype, same k, and every table's update is fused into the pass
+        batch_rows = (rows_pass and multi and div == 1 and len(self.live) > 1 and ROUTES.rows_multi
+                      and hasattr(ops, "decode_bwd_rows_adam_multi"))
+        jobs = []
         for n_st, st in enumerate(self.live):
             li = self.coders[st.layer]
             t = st.slot
@@ -650,6 +656,12 @@ class CLTEngine:
                     # unit-norm SAE decoder (sparse_coder.py:696-711): the finished gradient row is projected inside the
                     # pass; without the fused optimizer the caller projects W.grad before its step (tp.TPTrainer.step)
                     h = dict(h, project=True)
+                if batch_rows and h is not None:
+                    jobs.append(dict(seg=st.seg, acts=st.acts.pop(t).view(-1), v=st.v, W=W.data, grad_acts=st.gv,
+                                     post_enc=li.post_encs[t], post_scale=ps, want_g_post=need_pe, adam=h,
+                                     _pe=li.post_encs[t] if need_pe else None,
+                                     _ps=ps if need_pe and ps is not None and ps.requires_grad else None))
+                    continue
                 gW, gp, gs = ops.decode_bwd_rows(st.seg, st.acts.pop(t).view(-1), st.v, W.data, Gi, st.gv,
                                                  post_enc=li.post_encs[t], post_scale=ps, want_g_post=need_pe, adam=h)
                 if gW is not None:
@@ -672,6 +684,12 @@ class CLTEngine:
                 if ps is not None and ps.requires_grad:
                     self._acc_grad(ps, gs)
                 self._acc_grad(li.post_encs[t], gp)
+        if jobs:
+            for jb, (gp, gs) in zip(jobs, ops.decode_bwd_rows_adam_multi(jobs, G)):
+                if jb["_ps"] is not None:
+                    self._acc_grad(jb["_ps"], gs)
+                if jb["_pe"] is not None:
+                    self._acc_grad(jb["_pe"], gp)
 
         self._advance(acc_steps)
         self.last_fvu[j] = fvu

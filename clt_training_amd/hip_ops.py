@@ -48,6 +48,7 @@ class KernelProfile:
     def __init__(self, names=None):
         self.names = None if names is None else set(names)
         self.records = {}
+        self.units = {}  # name -> work units (e.g. row-pass jobs) summed over the recorded calls of batched entry points
         self.active = True  # bench.py switches it per step: every event pair costs ~10 us of idle GPU at a call boundary
 
     def add(self, name, start, end):
@@ -417,6 +418,55 @@ def decode_bwd_rows(seg: Segments, acts: Tensor, v: Tensor, W: Tensor, G: Tensor
           _ptr(g_scale), float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]), float(adam["eps"]),
           int(adam["step"]), int(bool(adam.get("project", False))), n, _ptr(ws), ws.numel(), _stream(W))
     return None, g_post, g_scale
+
+
+def decode_bwd_rows_adam_multi(jobs, G: Tensor):
+    """The decoder backward + Adam update of every live source of one target in ONE launch
+    (clt_decode_bwd_rows_adam_multi).  ``jobs``: dicts with seg, acts, v, W, grad_acts, adam (dict(m, v, lr, betas, eps,
+    step[, project]) -- the same hyper-parameters in every job), optionally post_enc, post_scale, want_g_post.  All jobs
+    share the table shape, k and the dtypes.  Returns a list of (g_post or None, g_scale or None) per job; bitwise the
+    results of one decode_bwd_rows(..., adam=...) call per job."""
+    G = _c(G)
+    j0 = jobs[0]
+    M, d = j0["W"].shape
+    a0 = j0["adam"]
+    n = j0["seg"].perm.numel()
+    outs, tabs, keep = [], [], []
+    for jb in jobs:
+        W, seg, ad = jb["W"], jb["seg"], jb["adam"]
+        acts, v, ga = _c(jb["acts"]), _c(jb["v"]), jb["grad_acts"]
+        assert W.shape == (M, d) and W.dtype == G.dtype and W.is_contiguous() and seg.M == M and seg.k == j0["seg"].k
+        assert acts.dtype == torch.float32 and acts.numel() == seg.perm.numel() == v.numel() == ga.numel() == n
+        assert v.dtype == j0["v"].dtype and ga.dtype == torch.float32 and ga.is_contiguous()
+        assert (ad["lr"], ad["betas"], ad["eps"], ad["step"], bool(ad.get("project", False))) == (
+            a0["lr"], a0["betas"], a0["eps"], a0["step"], bool(a0.get("project", False))), "one optimizer group per launch"
+        m_, v_ = ad["m"], ad["v"]
+        assert m_.dtype == W.dtype and v_.dtype == W.dtype and m_.shape == W.shape and v_.shape == W.shape
+        assert m_.is_contiguous() and v_.is_contiguous()
+        pe, ps = jb.get("post_enc"), jb.get("post_scale")
+        for t in (pe, ps):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+        g_post = torch.empty(M, dtype=torch.float32, device=W.device) if jb.get("want_g_post") else None
+        g_scale = torch.empty(M, dtype=torch.float32, device=W.device) if ps is not None else None
+        outs.append((g_post, g_scale))
+        tabs.append((seg.perm, seg.offsets, acts, v, pe, ps, W, m_, v_, ga, g_post, g_scale))
+        keep.append((acts, v))
+    lib = _lib.load()
+    step = _lib.CLT_ROWS_MAX_JOBS
+    for c0 in range(0, len(tabs), step):
+        grp = tabs[c0:c0 + step]
+        tab = (_lib.RowsJob * len(grp))()
+        for ent, fields in zip(tab, grp):
+            for (name, _), t in zip(_lib.RowsJob._fields_, fields):
+                setattr(ent, name, _ptr(t))
+        ws = workspace(G.device, lib.clt_rows_multi_workspace_bytes(n, d, len(grp)), "rows_multi")
+        _call("clt_decode_bwd_rows_adam_multi", C.cast(tab, C.c_void_p), len(grp), M, _dt(j0["v"]), _ptr(G), _dt(G), d,
+              j0["seg"].k, _dt(j0["W"]), float(a0["lr"]), float(a0["betas"][0]), float(a0["betas"][1]), float(a0["eps"]),
+              int(a0["step"]), int(bool(a0.get("project", False))), n, _ptr(ws), ws.numel(), _stream(G))
+        if PROFILE is not None and PROFILE.active:
+            PROFILE.units["clt_decode_bwd_rows_adam_multi"] = PROFILE.units.get("clt_decode_bwd_rows_adam_multi", 0) + len(grp)
+    del keep
+    return outs
 
 
 def rows_unit_norm(W: Tensor, eps: Optional[float] = None) -> Tensor:

@@ -245,6 +245,33 @@ int clt_decode_bwd_rows_adam(const int32_t* perm, const int32_t* offsets, int64_
                              int project_out, int64_t n_entries, void* workspace, size_t workspace_bytes,
                              clt_stream_t stream);
 
+/* The decoder backward of EVERY live source of one target (runner.py:43-71 in reverse: the same loss gradient G
+ * for all of them, one table W_decs[j - i] per source) as one launch: n_jobs clt_decode_bwd_rows_adam passes that
+ * share M, d, k, G, the dtypes and the Adam hyper-parameters; results are bitwise those of n_jobs separate calls.
+ * One ramp-up / tail and one long-segment helper launch per target instead of one per (source, target) pair.
+ * h_jobs is a HOST array (copied into the launch); workspace: clt_rows_multi_workspace_bytes(n_entries, d, n_jobs)
+ * or NULL (long segments then are walked by one wave each).                                                  */
+#define CLT_ROWS_MAX_JOBS 16
+typedef struct clt_rows_job {
+  const int32_t* perm;     /* the source's segments (clt_segments_build) */
+  const int32_t* offsets;
+  const float* acts;       /* [N*k] a' of this (source, target) pair */
+  const void* v;           /* [N*k] v_dtype */
+  const float* post_enc;   /* [M] or NULL */
+  const float* post_scale; /* [M] or NULL */
+  void* W;                 /* [M,d] w_dtype, updated in place */
+  void* exp_avg;
+  void* exp_avg_sq;
+  float* grad_acts;        /* [N*k], accumulated into */
+  float* g_post;           /* [M] or NULL */
+  float* g_scale;          /* [M] or NULL (requires post_scale) */
+} clt_rows_job;
+size_t clt_rows_multi_workspace_bytes(int64_t n_entries, int d, int n_jobs);
+int clt_decode_bwd_rows_adam_multi(const clt_rows_job* h_jobs, int n_jobs, int64_t M, int v_dtype, const void* G,
+                                   int g_dtype, int d, int k, int w_dtype, float lr, float b1, float b2, float eps,
+                                   int step, int project_out, int64_t n_entries, void* workspace,
+                                   size_t workspace_bytes, clt_stream_t stream);
+
 /* ------------------------------------------------------------------ SAE extras
  * Plain SAEs keep unit-norm decoder rows (sparse_coder.py:687-711; trainer.py:595-596, 793-795):
  *   clt_rows_unit_norm:   W[r,:] /= (||W[r,:]|| + eps)            (set_decoder_norm_to_unit_norm; eps = finfo(dtype).eps)

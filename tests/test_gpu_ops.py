@@ -802,3 +802,46 @@ def test_candidates_pack_unpack(ops, dtype):
     assert torch.equal(ui.cpu(), cand & 0xFFFFFFFF)
     pv, pi = ops.candidates_unpack(got, 1, k, dtype)
     assert torch.equal(pv.cpu(), v) and torch.equal(pi.cpu(), idx + off)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,d,M,k,n_jobs", [(600, 768, 2048, 16, 3), (300, 2048, 512, 8, 2), (257, 64, 300, 5, 5)])
+def test_decode_bwd_rows_adam_multi_equals_one_call_per_job(ops, dtype, N, d, M, k, n_jobs):
+    """clt_decode_bwd_rows_adam_multi (every live source of a target in one launch) is bitwise n_jobs separate
+    clt_decode_bwd_rows_adam calls: tables, both Adam moments, grad_acts, post-encoder sums -- with a long segment (one
+    latent on every token) in the first job, which goes through the batched long-row helper."""
+    g = torch.Generator().manual_seed(N + d)
+    G = torch.randn(N, d, generator=g).to(dtype).to(DEV)
+
+    def make():
+        gg = torch.Generator().manual_seed(7)
+        jobs = []
+        for j in range(n_jobs):
+            idx = torch.stack([torch.randperm(M, generator=gg)[:k] for _ in range(N)])
+            if j == 0:
+                idx[:, 0] = 11  # long segment (N > 512 in the first case)
+                idx[:, 1:] = 12 + idx[:, 1:] % (M - 12)
+                idx = torch.stack([torch.cat([r[:1], torch.unique(r[1:])[: k - 1]]) if torch.unique(r[1:]).numel() >= k - 1
+                                   else r for r in idx])
+            idx = idx.to(DEV)
+            v = torch.rand(N, k, generator=gg).to(dtype).to(DEV)
+            W = (0.1 * torch.randn(M, d, generator=gg)).to(dtype).to(DEV)
+            pe = (0.1 * torch.randn(M, generator=gg)).to(DEV)
+            ps = (1 + 0.1 * torch.randn(M, generator=gg)).to(DEV) if j % 2 == 0 else None
+            _, acts = ops.decode_fwd(idx, v, W, post_enc=pe, post_scale=ps, want_acts=True)
+            jobs.append(dict(seg=ops.segments_build(idx, M), acts=acts.view(-1), v=v, W=W,
+                             grad_acts=torch.randn(N, k, generator=gg).to(DEV), post_enc=pe, post_scale=ps, want_g_post=True,
+                             adam=dict(m=(0.01 * torch.randn(M, d, generator=gg)).to(dtype).to(DEV),
+                                       v=(0.001 * torch.rand(M, d, generator=gg)).to(dtype).to(DEV), lr=1e-3,
+                                       betas=(0.9, 0.999), eps=1e-8, step=3)))
+        return jobs
+
+    a, b = make(), make()
+    outs_a = ops.decode_bwd_rows_adam_multi(a, G)
+    for ja, jb, (gp_a, gs_a) in zip(a, b, outs_a):
+        _, gp_b, gs_b = ops.decode_bwd_rows(jb["seg"], jb["acts"], jb["v"], jb["W"], G, jb["grad_acts"],
+                                            post_enc=jb["post_enc"], post_scale=jb["post_scale"], want_g_post=True,
+                                            adam=jb["adam"])
+        assert torch.equal(ja["W"], jb["W"]) and torch.equal(ja["adam"]["m"], jb["adam"]["m"])
+        assert torch.equal(ja["adam"]["v"], jb["adam"]["v"]) and torch.equal(ja["grad_acts"], jb["grad_acts"])
+        assert torch.equal(gp_a, gp_b) and (gs_a is None) == (gs_b is None) and (gs_a is None or torch.equal(gs_a, gs_b))

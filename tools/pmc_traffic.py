@@ -17,6 +17,7 @@ csv.field_size_limit(1 << 30)
 
 # kernel-name substring -> the C-ABI entry point (or stage of it) the launch belongs to
 RULES = [
+    ("rows_lds_multi_kernel", "", "clt_decode_bwd_rows_adam_multi"),
     ("rows_lds_kernel", "Lb1EEE", "clt_decode_bwd_rows_adam"),
     ("rows_lds_kernel", "Lb0EEE", "clt_spt_dense_adam"),
     ("decode_fwd_multi_kernel", "", "clt_decode_fwd_multi"),
@@ -31,6 +32,9 @@ RULES = [
 ]
 
 
+JOBS = {}  # tag -> jobs per launch of a batched kernel (grid.y), when the CSV carries the grid
+
+
 def load(path, counter):
     per = {}
     with open(path, newline="") as f:
@@ -43,6 +47,8 @@ def load(path, counter):
                     if tag == "gemm_fast_kernel":  # split the GEMM launches by what they do: grid / LDS size tell
                         tag = f"gemm_fast_kernel<lds={row['LDS_Block_Size']}>"
                     per.setdefault(tag, []).append(float(row["Counter_Value"]))
+                    if "multi" in tag and row.get("Grid_Size_Y") and row.get("Workgroup_Size_Y"):
+                        JOBS[tag] = max(1, int(row["Grid_Size_Y"]) // max(1, int(row["Workgroup_Size_Y"])))
                     break
     return per
 
@@ -60,6 +66,9 @@ def main():
         w_med = statistics.median([v for v in wv if v > 0] or [0.0])
         kernels[tag] = {"launches": len(fv), "FETCH_SIZE_KiB": f_med, "WRITE_SIZE_KiB": w_med,
                         "hbm_bytes": int(1024 * (2 * f_med + w_med))}
+        if tag in JOBS:  # batched launch: the probe's launches hold JOBS[tag] (source, target) pairs each
+            kernels[tag]["jobs_per_launch"] = JOBS[tag]
+            kernels[tag]["hbm_bytes_per_job"] = kernels[tag]["hbm_bytes"] // JOBS[tag]
     # the fused encoder call = sample GEMM + sample top-k + filter GEMM + merge (its gated fallback launches fetch nothing)
     stages = [k for k in kernels if k.startswith("gemm_fast_kernel") or k in ("clt_topk_rows(sample)", "fused_select_kernel")]
     if stages:
