@@ -58,6 +58,8 @@ SIGNATURES = {
     "clt_encode_groupmax_fwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "clt_encode_topk_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "clt_encode_topk_fwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "clt_encode_topk_fwd_layers": (_i32, [_vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i32,
+                                          _vp, _vp, _sz, _vp]),
     "clt_decode_fwd": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _i32,
                               _vp]),
     "clt_decode_bwd_acts": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp,
@@ -109,6 +111,9 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+CLT_ERR_UNSUPPORTED = -2  # (include/clt_mi355.h)
 
 
 def check(rc: int, what: str):

@@ -408,3 +408,39 @@ extern "C" int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, c
   if (rc != CLT_OK) return rc;
   return clt_topk_rows(workspace, out_dtype, M, nullptr, nullptr, N, M, k, out_vals, out_dtype, out_idx, stream);
 }
+
+extern "C" int clt_encode_topk_fwd_layers(const void* x, int64_t x_row_stride, int64_t x_layer_stride,
+                                          const void* const* h_W, int in_dtype, const void* const* h_bias,
+                                          int bias_dtype, int n_layers, int64_t N_l, int64_t M, int d, int k,
+                                          void* out_vals, int out_dtype, int64_t* out_idx, void* workspace,
+                                          size_t workspace_bytes, clt_stream_t stream) {
+  CLT_CHECK_ARG(x && h_W && out_vals && out_idx && workspace && aligned16(workspace) && aligned16(x),
+                "clt_encode_topk_fwd_layers: null or misaligned pointer");
+  CLT_CHECK_ARG(n_layers >= 1 && N_l > 0 && M > 0 && d > 0 && k >= 1 && k <= M && valid_dtype(in_dtype) &&
+                    valid_dtype(out_dtype) && (!h_bias || valid_dtype(bias_dtype)),
+                "clt_encode_topk_fwd_layers: bad arguments");
+  for (int l = 0; l < n_layers; ++l)
+    CLT_CHECK_ARG(h_W[l] && aligned16(h_W[l]) && (!h_bias || (h_bias[l] && aligned16(h_bias[l]))),
+                  "clt_encode_topk_fwd_layers: layer %d: null or misaligned table / bias", l);
+  const int64_t N = N_l * n_layers;
+  // what the stacked launch needs: the bf16 fused path, whole 256-token tiles per layer, panels that do not straddle
+  // layers, 16-byte aligned x rows; anything else is for the caller to run layer by layer (clt_encode_topk_fwd)
+  const int64_t es = dtype_size(in_dtype);
+  const FusedPlan pl = fused_plan(in_dtype, out_dtype, N, M, d, k);
+  const size_t need = clt_encode_topk_workspace_bytes(N, M, out_dtype);
+  const size_t tail = fused_flag_bytes(N);
+  CLT_UNSUPPORTED(pl.ok && n_layers <= GEMM_MAX_LAYERS && N_l % (GEMM_TN * GEMM_PANEL) == 0 &&
+                      (x_row_stride * es) % 16 == 0 && (x_layer_stride * es) % 16 == 0 && x_row_stride >= d &&
+                      x_row_stride * es * GEMM_TN < (1ll << 31) && pl.bytes <= need - tail,
+                  "clt_encode_topk_fwd_layers: shape not taken by the stacked fused path (bf16, N_l %% %d == 0, <= %d layers)",
+                  GEMM_TN * GEMM_PANEL, GEMM_MAX_LAYERS);
+  if (workspace_bytes < need) {
+    set_error("clt_encode_topk_fwd_layers: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return CLT_ERR_WORKSPACE;
+  }
+  const FusedLayers fl = {n_layers, x_row_stride * es, x_layer_stride * es, h_W, h_bias};
+  char* ws = (char*)workspace;
+  return launch_fused_encode_topk(pl, x, h_W[0], h_bias ? h_bias[0] : nullptr, bias_dtype, N, M, d, k, out_vals, out_idx,
+                                  ws, (int*)(ws + need - tail), num_cus(), 0, (hipStream_t)stream, &fl);
+}
+

@@ -153,23 +153,34 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
   uint32_t voffW[4], voffX[4];
   const int nl = 64 * bias_esize / 16;  // lanes of the bias piece (this wave's 64 latents)
   const bool aux_lane = lane < nl || (MODE == 1 && lane >= 16 && lane < 48);
+  const int ntt_layer = p.ntt_layer;
+  const int ldx = ntt_layer ? (int)p.ldx_bytes : kbytes;  // bytes between consecutive token rows of x
   auto loader_tile = [&](int lt, int tt) {
     const int64_t lat0 = (int64_t)lt_actual(lt, p.lt_mode, p.lt_S) * GEMM_TM, tok0 = (int64_t)tt * GEMM_TN;
-    ldW = Wb + lat0 * kbytes;
-    ldX = xb + tok0 * kbytes;
+    const char* Wt = Wb;
+    const char* bt = bias;
+    if (ntt_layer) {  // stacked layers: this token tile's layer picks the table, the bias and the x block
+      const int layer = uni(tt / ntt_layer);
+      Wt = p.Wl[layer];
+      bt = p.biasl[layer];
+      ldX = xb + (int64_t)layer * p.x_layer_bytes + (int64_t)(tt - layer * ntt_layer) * GEMM_TN * ldx;
+    } else {
+      ldX = xb + tok0 * kbytes;
+    }
+    ldW = Wt + lat0 * kbytes;
     // rows past the end re-read the last row (their products are never stored)
     const int maxW = (int)(M - 1 - lat0 < GEMM_TM ? M - 1 - lat0 : GEMM_TM);
-    const int maxX = (int)(N - 1 - tok0 < GEMM_TN ? N - 1 - tok0 : GEMM_TN);
+    const int maxX = (int)(N - 1 - tok0 < GEMM_TN ? N - 1 - tok0 : GEMM_TN);  // (stacked layers: N_l % 256 == 0)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = (wave + 4 * q) * 16 + (lane >> 2);
       const int c = (lane & 3) ^ ((r >> 2) & 3);
       voffW[q] = (uint32_t)((r < maxW ? r : maxW) * kbytes + c * 16);
-      voffX[q] = (uint32_t)((r < maxX ? r : maxX) * kbytes + c * 16);
+      voffX[q] = (uint32_t)((r < maxX ? r : maxX) * ldx + c * 16);
     }
     const int epc = 16 / bias_esize;
     const int64_t lat = lat0 + 64 * wave + lane * epc;
-    ldA = (bias && lat + epc <= M) ? bias + lat * bias_esize : zero;
+    ldA = (bt && lat + epc <= M) ? bt + lat * bias_esize : zero;
     if (MODE == 1 && lane >= 16 && lane < 48)  // tau is padded to a multiple of 256 tokens
       ldA = reinterpret_cast<const char*>(p.tau + tok0 + wn * 128 + (lane - 16) * 4);
   };
@@ -283,9 +294,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
         else if (allow >= 27) asm volatile("s_waitcnt vmcnt(27)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
       }
+#ifdef CLT_TUNING  // ablations (results are garbage): 8 = no fragment reads, 4 = no LDS-DMA after the prologue
+      if (!(dbg & 8)) {
+        if (t < 8) read_piece(cb, 1, t, A1, B1);
+        if (t >= 16 && t < 24) read_piece(nb, 0, t - 16, A0, B0);
+      }
+      if (!(dbg & 4) && t % 3 == 2 && t <= 26) dma((t - 2) / 3, ld_stage, kb0);
+#else
       if (t < 8) read_piece(cb, 1, t, A1, B1);
       if (t >= 16 && t < 24) read_piece(nb, 0, t - 16, A0, B0);
       if (t % 3 == 2 && t <= 26) dma((t - 2) / 3, ld_stage, kb0);
+#endif
       CLT_FENCE();
     }
     loader_advance();
@@ -649,8 +668,17 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
 
 int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, const void* bias, int bias_dtype,
                              int64_t N, int64_t M, int d, int k, void* out_vals, int64_t* out_idx, char* ws, int* flag,
-                             int cus, int dbg, hipStream_t st) {
+                             int cus, int dbg, hipStream_t st, const FusedLayers* layers) {
   FastArgs a = {};
+  if (layers) {  // N = n_layers * N_l stacked tokens; every launch below sees one problem of N tokens
+    a.ntt_layer = (int)(N / layers->n_layers / GEMM_TN);
+    a.ldx_bytes = layers->ldx_bytes;
+    a.x_layer_bytes = layers->x_layer_bytes;
+    for (int l = 0; l < layers->n_layers; ++l) {
+      a.Wl[l] = (const char*)layers->W[l];
+      a.biasl[l] = layers->bias ? (const char*)layers->bias[l] : nullptr;
+    }
+  }
   a.x = (const char*)x;
   a.W = (const char*)W;
   a.bias = (const char*)bias;

@@ -9,6 +9,7 @@ constexpr int GEMM_TM = 256;   // latents per tile
 constexpr int GEMM_TN = 256;   // tokens per tile
 constexpr int GEMM_PANEL = 8;  // token tiles per L2 panel
 constexpr int FUSED_SLOTS = 8; // entries per candidate list (64 latents of one token)
+constexpr int GEMM_MAX_LAYERS = 16;
 
 enum { LT_ALL = 0, LT_SAMPLE = 1, LT_REST = 2 };
 
@@ -50,6 +51,14 @@ struct FastArgs {
   uint8_t* counts;
   int nL;
   int qflush;         // filter mode: turn the hit queue into list entries after every quarter tile, not once per tile
+  // Several layers in one launch (same N_l, M, d; each layer its own W and bias): the layers' tokens are stacked, token
+  // tile tt belongs to layer tt / ntt_layer (ntt_layer = N_l / 256; 0 = one layer: W / bias above).  x row t of layer l
+  // starts at x + l * x_layer_bytes + t * ldx_bytes (a [N_l, L * d] block of layer inputs side by side: ldx = L * d * 2,
+  // x_layer_bytes = d * 2).  Everything else -- tau, lists, counts, pre, outputs -- is indexed by the stacked token id.
+  int ntt_layer;
+  int64_t ldx_bytes, x_layer_bytes;
+  const char* Wl[GEMM_MAX_LAYERS];
+  const char* biasl[GEMM_MAX_LAYERS];
   const int* gate;    // if set, the kernel returns at once unless *gate != 0 ...
   const int* tt_map;  // ... and, if tt_map is set too, *gate is the number of token tiles to do and tt_map[i] their ids
   int dbg;
@@ -83,8 +92,15 @@ inline size_t fused_flag_bytes(int64_t N) {
   const int64_t ntt = (N + GEMM_TN - 1) / GEMM_TN;
   return align_up((size_t)(1 + 2 * (ntt > 0 ? ntt : 0)) * sizeof(int), 4096);
 }
+// layers: null for one layer; else n_layers tables / biases and the x strides (FastArgs), N = n_layers * N_l stacked tokens
+struct FusedLayers {
+  int n_layers;
+  int64_t ldx_bytes, x_layer_bytes;
+  const void* const* W;
+  const void* const* bias;
+};
 int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, const void* bias, int bias_dtype,
                              int64_t N, int64_t M, int d, int k, void* out_vals, int64_t* out_idx, char* ws, int* flag,
-                             int cus, int dbg, hipStream_t st);
+                             int cus, int dbg, hipStream_t st, const FusedLayers* layers = nullptr);
 
 }  // namespace clt

@@ -195,6 +195,46 @@ def encode_topk(x: Tensor, W: Tensor, b: Optional[Tensor], k: int, out_dtype=Non
     return ov, oi
 
 
+def encode_topk_layers(xbuf: Tensor, Ws, bs, k: int):
+    """``encode_topk`` for several layers of one shape in ONE set of launches (clt_encode_topk_fwd_layers).
+    ``xbuf`` [N, L * d]: the layers' inputs side by side (layer l = columns [l * d, (l + 1) * d)); ``Ws`` / ``bs``: the
+    L encoder tables [M, d] and biases [M] (or None).  Returns values [L, N, k] and int64 indices [L, N, k], bit for bit
+    those of L separate calls; None when the stacked path does not take the shape (the caller goes layer by layer)."""
+    L = len(Ws)
+    N, Ld = xbuf.shape
+    d = Ld // L
+    M = Ws[0].shape[0]
+    if (L < 1 or L > 16 or Ld != L * d or N % 2048 != 0 or xbuf.dtype != torch.bfloat16 or not xbuf.is_contiguous()
+            or any(W.shape != (M, d) or W.dtype != xbuf.dtype or not W.is_contiguous() for W in Ws)):
+        return None
+    have_b = bs is not None and bs[0] is not None
+    if have_b and any(b is None or b.dtype != bs[0].dtype or not b.is_contiguous() for b in bs):
+        return None
+    lib = _lib.load()
+    ws = workspace(xbuf.device, lib.clt_encode_topk_workspace_bytes(L * N, M, _DT[xbuf.dtype]), "pre")
+    ov = torch.empty(L, N, k, dtype=xbuf.dtype, device=xbuf.device)
+    oi = torch.empty(L, N, k, dtype=torch.int64, device=xbuf.device)
+    wtab = (C.c_void_p * L)(*[W.data_ptr() for W in Ws])
+    btab = (C.c_void_p * L)(*[b.data_ptr() for b in bs]) if have_b else None
+    fn = lib.clt_encode_topk_fwd_layers
+    prof = PROFILE
+    timed = prof is not None and prof.active
+    if timed:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+    rc = fn(_ptr(xbuf), Ld, d, C.cast(wtab, C.c_void_p), _dt(xbuf), C.cast(btab, C.c_void_p) if have_b else None,
+            _dt(bs[0]) if have_b else 0, L, N, M, d, k, _ptr(ov), _DT[xbuf.dtype], _ptr(oi), _ptr(ws), ws.numel(),
+            _stream(xbuf))
+    if rc == _lib.CLT_ERR_UNSUPPORTED:
+        return None
+    if timed:
+        e.record()
+        prof.add("clt_encode_topk_fwd_layers", s, e)
+        prof.units["clt_encode_topk_fwd_layers"] = prof.units.get("clt_encode_topk_fwd_layers", 0) + L
+    check(rc, "clt_encode_topk_fwd_layers")
+    return ov, oi
+
+
 def encode_topk_fallback_tiles(x: Tensor, M: int, out_dtype=None):
     """Diagnostics (tools/, tests; SYNCHRONISES): after an ``encode_topk(x, W[M, d], ...)`` call on this device, how many
     of its 256-token tiles went through the exact fallback (plain GEMM + row top-k) -> (flagged tiles, all tiles).

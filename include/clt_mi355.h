@@ -68,6 +68,19 @@ int clt_topk_rows(const void* vals, int val_dtype, int64_t ld, const int64_t* ca
                   int64_t N, int64_t L, int k, void* out_vals, int out_dtype, int64_t* out_idx,
                   clt_stream_t stream);
 
+/* clt_encode_topk_fwd for n_layers layers of the same shape in ONE set of launches (all layer inputs of a step are known
+ * at its start, and no encoder reads what a decoder writes within the step: trainer.py:492-545 encodes them one hook at
+ * a time only because the hooks fire that way).  Layer l reads x + l * x_layer_stride + t * x_row_stride (elements; a
+ * block of layer inputs side by side has x_row_stride = n_layers * d, x_layer_stride = d), multiplies with h_W[l]
+ * (HOST array of device pointers) and adds h_bias[l]; outputs are stacked: out_vals / out_idx [n_layers * N_l, k].
+ * Results are those of n_layers clt_encode_topk_fwd calls bit for bit.  Takes bf16 operands on the fused path with
+ * N_l a multiple of 2048 and at most 16 layers (CLT_ERR_UNSUPPORTED otherwise: call layer by layer).  workspace:
+ * clt_encode_topk_workspace_bytes(n_layers * N_l, M, out_dtype).                                                    */
+int clt_encode_topk_fwd_layers(const void* x, int64_t x_row_stride, int64_t x_layer_stride, const void* const* h_W,
+                               int in_dtype, const void* const* h_bias, int bias_dtype, int n_layers, int64_t N_l,
+                               int64_t M, int d, int k, void* out_vals, int out_dtype, int64_t* out_idx,
+                               void* workspace, size_t workspace_bytes, clt_stream_t stream);
+
 /* The exchange format of the TP top-k merge (fused_encoder.py:347-360 all-gathers values and int64 indices as two
  * tensors; here one int64 per candidate carries both through ONE collective):
  *   packed = (bits of float32(value) << 32) | (idx + idx_offset),  values >= 0, idx + idx_offset < 2^32.

@@ -845,3 +845,21 @@ def test_decode_bwd_rows_adam_multi_equals_one_call_per_job(ops, dtype, N, d, M,
         assert torch.equal(ja["W"], jb["W"]) and torch.equal(ja["adam"]["m"], jb["adam"]["m"])
         assert torch.equal(ja["adam"]["v"], jb["adam"]["v"]) and torch.equal(ja["grad_acts"], jb["grad_acts"])
         assert torch.equal(gp_a, gp_b) and (gs_a is None) == (gs_b is None) and (gs_a is None or torch.equal(gs_a, gs_b))
+
+
+@pytest.mark.parametrize("L,N,M,d,k,bias", [(3, 2048, 12288, 768, 32, True), (2, 2048, 16384, 256, 64, False)])
+def test_encode_topk_layers_equals_layer_by_layer(ops, L, N, M, d, k, bias):
+    """clt_encode_topk_fwd_layers (all layers' encoders stacked into one set of launches, inputs read in place from the
+    side-by-side [N, L * d] block) is bit for bit L separate clt_encode_topk_fwd calls; shapes the stacked path does not
+    take return None."""
+    g = torch.Generator(device=DEV).manual_seed(L * N + M)
+    xbuf = torch.randn(N, L * d, device=DEV, generator=g).to(torch.bfloat16)
+    Ws = [(torch.randn(M, d, device=DEV, generator=g) / d**0.5).to(torch.bfloat16) for _ in range(L)]
+    bs = [0.1 * torch.randn(M, device=DEV, generator=g) for _ in range(L)] if bias else None
+    out = ops.encode_topk_layers(xbuf, Ws, bs, k)
+    assert out is not None
+    v, i = out
+    for l in range(L):
+        vr, ir = ops.encode_topk(xbuf[:, l * d:(l + 1) * d].contiguous(), Ws[l], bs[l] if bias else None, k)
+        assert torch.equal(i[l], ir) and torch.equal(v[l], vr), l
+    assert ops.encode_topk_layers(xbuf[:300].contiguous(), Ws, bs, k) is None  # N_l not a multiple of 2048
