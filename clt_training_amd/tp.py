@@ -94,6 +94,9 @@ class TPTrainer(FitLoop):
         overlap = ((self.comm.world > 1 or ROUTES.overlap_single) and self.device.type == "cuda"
                    and self.global_step > 0 and ROUTES.overlap)
         pending = {}
+        pre = None
+        if not overlap and (self.global_step > 0 or bool(cfg.finetune)):  # (step 0: data-dependent init, layer by layer)
+            pre = eng.encode_all([batch[name][0] for name in names])
         if overlap:
             main = torch.cuda.current_stream(self.device)
             if self._enc_stream is None:
@@ -121,7 +124,7 @@ class TPTrainer(FitLoop):
                     self.ops.rows_unit_norm(W.data)
                 else:
                     W.data /= W.data.norm(dim=1, keepdim=True) + torch.finfo(W.dtype).eps
-            enc = None
+            enc = pre[j] if pre is not None else None
             if overlap:
                 if j + 1 < len(names):
                     launch_encode(j + 1)

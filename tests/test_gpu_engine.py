@@ -303,3 +303,55 @@ def test_engine_vs_reference_golden(name):
             # the kernel the library picks on the box) carries an error relative to its terms
             atol = max(2e-7, 1e-5 * float(ref.abs().max()))
             torch.testing.assert_close(got[n].grad.float().cpu(), ref, rtol=1e-5, atol=atol, msg=lambda m: f"{l}.{n}: {m}")
+
+
+def test_engine_stacked_encoders_equal_layer_by_layer(monkeypatch):
+    """engine.ROUTES.enc_layers (all layers' fused encode + top-k stacked into one set of launches from step 1 on:
+    clt_encode_topk_fwd_layers) leaves every step bit for bit what the layer-by-layer encoders give: fvu and every
+    parameter after 3 steps of a 3-layer bf16 CLT with skip connections at N = 2048 tokens."""
+    from clt_training_amd import SparseCoderConfig, TrainConfig
+    from clt_training_amd.tp import TPTrainer
+
+    L, d, N, k, M = 3, 256, 2048, 16, 4096
+    hooks = [f"h.{i}" for i in range(L)]
+    g = torch.Generator().manual_seed(11)
+    batches = []
+    for s in range(3):
+        b = {}
+        for h in hooks:
+            x = torch.randn(N, d, generator=g) + 0.1 * torch.randn(d, generator=g)
+            b[h] = (x.bfloat16().to(DEV), (0.5 * x + 0.5 * torch.randn(N, d, generator=g)).bfloat16().to(DEV))
+        b["loss_mask"] = (torch.rand(N, generator=g) > 0.1).to(DEV)
+        batches.append(b)
+    calls = []
+
+    def run(stacked):
+        monkeypatch.setattr(ROUTES, "enc_layers", stacked)
+        torch.manual_seed(0)
+        cfg = TrainConfig(sae=SparseCoderConfig(dtype="bfloat16", num_latents=M, k=k, transcode=True, skip_connection=True),
+                          hookpoints=list(hooks), cross_layer=L, optimizer="adam", lr=1e-3, lr_warmup_steps=1,
+                          log_to_wandb=False)
+        tr = TPTrainer(cfg, batches, device=DEV, num_batches=10)
+        real = tr.engine.encode_all
+
+        def spy(xs):
+            out = real(xs)
+            calls.append((stacked, out is not None))
+            return out
+
+        tr.engine.encode_all = spy
+        with torch.no_grad():
+            gg = torch.Generator(device=DEV).manual_seed(1)
+            for sae in tr.saes.values():
+                for n, p in sae.named_parameters():
+                    if n.startswith("W_dec"):
+                        p.copy_((0.02 * torch.randn(p.shape, generator=gg, device=DEV)).to(p.dtype))
+        fv = [{h: float(v) for h, v in tr.step(b).items()} for b in batches]
+        return fv, {f"{h}.{n}": p.detach().clone() for h, sae in tr.saes.items() for n, p in sae.named_parameters()}
+
+    fv_a, pa = run(True)
+    fv_b, pb = run(False)
+    assert calls.count((True, True)) == 2 and (False, True) not in calls  # steps 1 and 2 took the stacked path
+    assert fv_a == fv_b
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
