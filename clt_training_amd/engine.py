@@ -79,7 +79,7 @@ def _mm_f32(a: Tensor, b: Tensor) -> Tensor:
             _MM_OUT_DTYPE = False
     if _MM_OUT_DTYPE:
         return torch.mm(a, b, out_dtype=torch.float32)
-    return (a @ b).float()
+    return a.float() @ b.float()  # (no out_dtype on this device / build: still one rounding-free fp32 product)
 
 
 # --------------------------------------------------------------------------- collectives

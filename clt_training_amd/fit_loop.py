@@ -55,8 +55,20 @@ class FitLoop:
 
     # ------------------------------------------------------------------ optimizers (trainer.py:151-254)
     @staticmethod
-    def build_optimizers(cfg, param_lists, num_latents, num_batches, adam_cls=None, signsgd_cls=None):
+    def build_optimizers(cfg, param_lists, num_latents, num_batches, adam_cls=None, signsgd_cls=None, muon_kw=None):
         """One parameter group per sparse coder with the reference's LR rule; -> (optimizers, lr_schedulers)."""
+        if cfg.optimizer == "muon":  # trainer.py:194-222: Muon for the matrices, Adam for the vectors, two schedules
+            from .muon import Muon
+
+            if adam_cls is None:
+                from .adam import Adam as adam_cls
+            params = [p for ps in param_lists for p in ps]
+            mats = [p for p in params if p.ndim >= 2]
+            lr = cfg.lr or 2e-3  # "Muon LR is independent of the number of latents"
+            opts = [Muon(mats, lr=lr, **(muon_kw or {})),
+                    adam_cls([dict(params=[p for p in params if p.ndim < 2], lr=torch.tensor(lr))], betas=(cfg.b1, cfg.b2))]
+            return opts, [WarmupLinearSchedule(opts[0], 0, num_batches),
+                          WarmupLinearSchedule(opts[1], cfg.lr_warmup_steps, num_batches)]
         if cfg.optimizer in ("adam", "adam8"):
             if cfg.optimizer == "adam8":  # trainer.py:155-164: torchao's AdamW8bit when importable, else plain Adam
                 print("torchao 8-bit Adam not available, using Adam")

@@ -57,10 +57,15 @@ class TPTrainer(FitLoop):
         if num_batches is None:
             num_batches = len(dataset)
         # trainer.py:166-173: the FULL latent count sets the LR
+        muon_kw = None
+        if cfg.optimizer == "muon":  # the [M_local, d] tables are row blocks of the full matrices (muon.newton_schulz)
+            tables = [p for s in self.saes.values() for p in [s.W_enc, *s.W_decs] if p.requires_grad]
+            muon_kw = dict(comm=self.comm, sharded={id(p) for p in tables},
+                           full_rows={id(p): p.shape[0] * self.comm.world for p in tables})
         self.optimizers, self.lr_schedulers = self.build_optimizers(
             cfg, [[p for p in sae.parameters() if p.requires_grad] for sae in self.saes.values()],
             [sae.num_latents for sae in self.saes.values()], num_batches, adam_cls=optimizer_cls,
-            signsgd_cls=getattr(ops, "SignSGD", None))
+            signsgd_cls=getattr(ops, "SignSGD", None), muon_kw=muon_kw)
         opt = self.optimizers[0]
         # Decoder / encoder row gradients go straight into the optimizer update (no .grad round trip) when nothing
         # else consumes them: one micro-step per optimizer step, and an optimizer that has the fused form (Adam).
@@ -187,13 +192,20 @@ class TPTrainer(FitLoop):
         for name, sae in self.saes.items():
             if only is None or name in only:
                 sae.save_to_disk(path / name, self.comm)
-        flat = self._gathered_optimizer_state()  # collective: every rank takes part, rank 0 gets the dict
-        if rank == 0:
-            torch.save(flat, path / "optimizer_0.pt")
+        if self.cfg.optimizer == "muon":
+            # Muon + Adam: each rank keeps its shard's state (resumes on the same tp degree only; the gathered,
+            # reference-layout file below is written for the single-optimizer configurations)
+            for i, opt in enumerate(self.optimizers):
+                torch.save(opt.state_dict(), path / f"optimizer_{i}.rank{rank}.pt")
+        else:
+            flat = self._gathered_optimizer_state()  # collective: every rank takes part, rank 0 gets the dict
+            if rank == 0:
+                torch.save(flat, path / "optimizer_0.pt")
         torch.save({"num_tokens_since_fired": {h: t.cpu() for h, t in self.num_tokens_since_fired.items()},
                     "best_loss": self.best_loss}, path / f"rank_{rank}_state.pt")
         if rank == 0:
-            torch.save(self.lr_schedulers[0].state_dict(), path / "lr_scheduler_0.pt")
+            for i, sch in enumerate(self.lr_schedulers):
+                torch.save(sch.state_dict(), path / f"lr_scheduler_{i}.pt")
             torch.save({"global_step": self.global_step}, path / "state.pt")
         if self.comm.world > 1:
             dist.barrier(group=self.comm.group)
@@ -211,8 +223,14 @@ class TPTrainer(FitLoop):
                     p.copy_(q.to(p.dtype))
                 for (_, b), (_, c) in zip(sae.named_buffers(), loaded.named_buffers()):
                     b.copy_(c)
-        self._scatter_optimizer_state(torch.load(path / "optimizer_0.pt", map_location="cpu", weights_only=True))
-        self.lr_schedulers[0].load_state_dict(torch.load(path / "lr_scheduler_0.pt", weights_only=True))
+        if self.cfg.optimizer == "muon":
+            for i, opt in enumerate(self.optimizers):
+                opt.load_state_dict(torch.load(path / f"optimizer_{i}.rank{rank}.pt", map_location=self.device,
+                                               weights_only=True))
+        else:
+            self._scatter_optimizer_state(torch.load(path / "optimizer_0.pt", map_location="cpu", weights_only=True))
+        for i, sch in enumerate(self.lr_schedulers):
+            sch.load_state_dict(torch.load(path / f"lr_scheduler_{i}.pt", weights_only=True))
         self.global_step = torch.load(path / "state.pt", weights_only=True)["global_step"]
         fired = torch.load(path / f"rank_{rank}_state.pt", map_location=self.device, weights_only=True)
         for h, t in fired["num_tokens_since_fired"].items():

@@ -73,8 +73,12 @@ class Trainer(FitLoop):
         if num_batches is None:
             num_batches = len(dataset)
         # ---- optimizer (trainer.py:151-254)
+        # (optimizer="muon": the reference orders every coder's parameters by NAME, trainer.py:195-199 -- the order the
+        # positions in its optimizer_{0,1}.pt refer to)
+        by_name = cfg.optimizer == "muon"
         self.optimizers, self.lr_schedulers = self.build_optimizers(
-            cfg, [list(sae.parameters()) for sae in self.saes.values()],
+            cfg, [[p for _, p in sorted(sae.named_parameters())] if by_name else list(sae.parameters())
+                  for sae in self.saes.values()],
             [sae.num_latents for sae in self.saes.values()], num_batches)
         # Row gradients of the [M, d] matrices go straight into the Adam update inside the gradient kernels when each
         # optimizer step sees one micro-step (fused_state): no dense .grad, no second pass over the tables.
@@ -191,9 +195,14 @@ class Trainer(FitLoop):
             if only is None or name in only:
                 sae.save_to_disk(f"{path}/{name}")
         # optimizer_0.pt in the reference's flattened layout (utils.py:193-277; trainer.py:931-937)
-        opt = self.optimizers[0]
-        torch.save(ckpt.to_reference_layout(opt.state_dict(), getattr(opt, "_step", 0)), path / "optimizer_0.pt")
-        torch.save(self.lr_schedulers[0].state_dict(), path / "lr_scheduler_0.pt")
+        for i, opt in enumerate(self.optimizers):  # (optimizer="muon": Muon for the matrices, Adam for the vectors)
+            if hasattr(opt, "_step"):
+                flat = ckpt.to_reference_layout(opt.state_dict(), opt._step)
+            else:
+                flat = ckpt.flatten_state(opt.state_dict())
+            torch.save(flat, path / f"optimizer_{i}.pt")
+        for i, sch in enumerate(self.lr_schedulers):
+            torch.save(sch.state_dict(), path / f"lr_scheduler_{i}.pt")
         torch.save({"global_step": self.global_step}, path / "state.pt")
         self.save_config(path)
         torch.save({"num_tokens_since_fired": {h: t.cpu() for h, t in self.num_tokens_since_fired.items()},
@@ -212,13 +221,16 @@ class Trainer(FitLoop):
         for h, v in rank_state.get("best_loss", {}).items():
             if h in self.best_loss:
                 self.best_loss[h] = v
-        self.lr_schedulers[0].load_state_dict(torch.load(path / "lr_scheduler_0.pt", weights_only=True))
-        nested, step = ckpt.from_file_layout(torch.load(path / "optimizer_0.pt", map_location=self.device, weights_only=True))
-        self.optimizers[0].load_state_dict(nested)  # (written by the reference or by save(): the same layout)
-        if step is not None:
-            self.optimizers[0]._step = step
+        for i, sch in enumerate(self.lr_schedulers):
+            sch.load_state_dict(torch.load(path / f"lr_scheduler_{i}.pt", weights_only=True))
+        for i, opt in enumerate(self.optimizers):
+            nested, step = ckpt.from_file_layout(torch.load(path / f"optimizer_{i}.pt", map_location=self.device,
+                                                            weights_only=True))
+            opt.load_state_dict(nested)  # (written by the reference or by save(): the same layout)
+            if step is not None and hasattr(opt, "_step"):
+                opt._step = step
         for name, sae in self.saes.items():
-            if (path / name).exists():
+            if (path / name / "sae.safetensors").exists():
                 sae.load_state(f"{path}/{name}")
             else:
                 print(f"No checkpoint found for {name} at {path}, skipping")

@@ -272,7 +272,39 @@ def golden_clt(name, cfg_kw, L, cross, N, d, seed):
 
 
 # ---------------------------------------------------------------- the reference Trainer itself
-def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3, warmup=2):
+def golden_muon(name="muon_steps"):
+    """The reference's Muon (sparsify/muon.py:51-203, ddp=False) on three matrices -- tall, square, wide -- for three
+    steps with recorded gradients, and its quintic Newton-Schulz iteration (muon.py:13-42) on a tall matrix.  The
+    function is decorated with torch.compile; dynamo is switched off so that it runs its Python body eagerly."""
+    import torch._dynamo as dynamo
+
+    dynamo.config.disable = True
+    from sparsify.muon import Muon, quintic_newtonschulz
+
+    g = torch.Generator().manual_seed(31)
+    shapes = [(96, 16), (16, 16), (8, 24)]
+    ps = [torch.nn.Parameter(0.1 * torch.randn(s, generator=g)) for s in shapes]
+    t = {f"p0.{i}": p.detach().clone() for i, p in enumerate(ps)}
+    opt = Muon(ps, lr=2e-3, ddp=False)
+    for s in range(3):
+        for i, p in enumerate(ps):
+            gr = torch.randn(p.shape, generator=g)
+            t[f"g{s}.{i}"] = gr.clone()  # (the optimizer's Nesterov lerp_ overwrites .grad)
+            p.grad = gr
+        opt.step()
+        for i, p in enumerate(ps):
+            t[f"p{s + 1}.{i}"] = p.detach().clone()
+    G = torch.randn(96, 16, generator=g)
+    t["ns_in"] = G.clone()
+    t["ns_out"] = quintic_newtonschulz(G, 5).float()
+    G2 = torch.randn(8, 24, generator=g)
+    t["ns_in_wide"] = G2.clone()
+    t["ns_out_wide"] = quintic_newtonschulz(G2, 5).float()
+    save(name, t, dict(lr=2e-3, momentum=0.95, nesterov=True, weight_decay=0.1, ns_steps=5, steps=3, n_params=3,
+                       ref="muon.py:13-42, 51-203 (ddp=False)"))
+
+
+def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3, warmup=2, optimizer="adam"):
     """Drive the reference ``Trainer.fit`` (trainer.py:61-254, 376-865; mesh=None, optimizer="adam", FVU loss) on a
     random-init GPT-2 built from a config (no download) for ``steps`` batches, and record what pins SURVEY.md rows
     a18-a20, a22: the coders' parameters as constructed, after the data-dependent step-0 init (captured at the first
@@ -298,7 +330,11 @@ def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3,
     ids = torch.randint(1, 96, (B * steps, T), generator=g)
     ds = Dataset.from_dict({"input_ids": ids.tolist()}).with_format("torch")
     tmp = tempfile.mkdtemp()
-    cfg = TrainConfig(sae=SparseCoderConfig(**sae_kw), batch_size=B, optimizer="adam", lr=1e-2, lr_warmup_steps=warmup,
+    if optimizer == "muon":
+        import torch._dynamo as dynamo
+
+        dynamo.config.disable = True  # muon.py:12: torch.compile'd Newton-Schulz, run eagerly
+    cfg = TrainConfig(sae=SparseCoderConfig(**sae_kw), batch_size=B, optimizer=optimizer, lr=1e-2, lr_warmup_steps=warmup,
                       b1=b1, hookpoints=["h.*.mlp"], cross_layer=cross, remove_first_token=True, save_every=10**9,
                       # filter_bos=True skips `bos_mask &= 0` (trainer.py:687-688), which torch 2.10 rejects (Long into
                       # Bool); no token id equals bos_token_id here, so the mask is the same: first tokens only
@@ -328,11 +364,11 @@ def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3,
         return orig_forward(*a, **k)
 
     model.forward = forward
-    opt = tr.optimizers[0]
-    orig_step = opt.step
+    opt, last = tr.optimizers[0], tr.optimizers[-1]  # (optimizer="muon": Muon steps first, then Adam)
+    orig_step, orig_last = opt.step, last.step
     n_step = [0]
 
-    def step(*a, **k):
+    def before():
         s = n_step[0]
         for l, h in enumerate(hooks):
             if s == 0:
@@ -340,15 +376,30 @@ def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3,
                     t[f"init.{l}.{n}"] = p.detach().clone()
             for n, p in tr.saes[h].named_parameters():
                 t[f"grad{s}.{l}.{n}"] = p.grad.detach().clone()
-        t[f"lr{s}"] = torch.tensor([float(pg["lr"]) for pg in opt.param_groups])
-        out = orig_step(*a, **k)
+        t[f"lr{s}"] = torch.tensor([float(pg["lr"]) for o in tr.optimizers for pg in o.param_groups])
+
+    def after():
+        s = n_step[0]
         for l, h in enumerate(hooks):
             for n, p in tr.saes[h].state_dict().items():
                 t[f"after{s}.{l}.{n}"] = p.detach().clone()
         n_step[0] += 1
+
+    def step(*a, **k):
+        before()
+        out = orig_step(*a, **k)
+        if last is opt:
+            after()
+        return out
+
+    def step_last(*a, **k):
+        out = orig_last(*a, **k)
+        after()
         return out
 
     opt.step = step
+    if last is not opt:
+        last.step = step_last
     ckpt_note = "written by Trainer.fit's final save (trainer.py:861, 910-964)"
     try:
         tr.fit()
@@ -362,8 +413,9 @@ def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3,
 
         path = f"{tmp}/run"
         os.makedirs(path, exist_ok=True)
-        save_sharded(opt.state_dict(), f"{path}/optimizer_0.pt", None, save_st=False, unflatten=True)
-        torch.save(tr.lr_schedulers[0].state_dict(), f"{path}/lr_scheduler_0.pt")
+        for i, (o, sch) in enumerate(zip(tr.optimizers, tr.lr_schedulers)):
+            save_sharded(o.state_dict(), f"{path}/optimizer_{i}.pt", None, save_st=False, unflatten=True)
+            torch.save(sch.state_dict(), f"{path}/lr_scheduler_{i}.pt")
         torch.save({"global_step": tr.global_step}, f"{path}/state.pt")
         torch.save({"num_tokens_since_fired": tr.num_tokens_since_fired, "best_loss": tr.best_loss},
                    f"{path}/rank_0_state.pt")
@@ -383,7 +435,7 @@ def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3,
     mask[:, 0] = False  # remove_first_token (trainer.py:689-690, 609)
     t["mask"] = mask.flatten()
     save(name, t, dict(cfg=sae_kw, L=L, d=d, cross_layer=cross, b1=b1, lr=1e-2, warmup=warmup, steps=steps,
-                       tokens_per_step=B * T, hooks=hooks, seed=seed, num_batches=steps,
+                       tokens_per_step=B * T, hooks=hooks, seed=seed, num_batches=steps, optimizer=optimizer,
                        dead_feature_threshold=B * T, checkpoint=ckpt_note,
                        ref="trainer.py:61-254, 376-865 (fit, mesh=None)"))
     dst = OUT / f"{name}_ckpt"
@@ -400,6 +452,11 @@ def main(only=None):
         golden_trainer("trainer_clt_b1_09", clt, cross=2, b1=0.9, seed=21)
         golden_trainer("trainer_clt_b1_00", dict(clt, normalize_io=True), cross=3, b1=0.0, seed=22)
         golden_trainer("trainer_sae_b1_09", dict(expansion_factor=8, k=4, transcode=False), cross=0, b1=0.9, seed=23)
+        return
+    if only == "muon":
+        golden_muon()
+        golden_trainer("trainer_clt_muon", dict(expansion_factor=8, k=4, transcode=True, skip_connection=True), cross=2,
+                       b1=0.9, seed=24, optimizer="muon")
         return
     if only == "groupmax":  # added later: leaves the earlier fixtures untouched
         golden_encoder("encoder_groupmax", N=24, d=48, M=512, k=8, seed=12, activation="groupmax")
