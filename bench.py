@@ -100,7 +100,7 @@ def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.
         return es * N * (k + 1) * d, "byte"
     if name == "clt_spt_dense":
         return es * (M * d + N * k / world * d), "byte"
-    if name == "clt_spt_dense_adam":  # gathered rows + read/write of the parameter, exp_avg and exp_avg_sq rows
+    if name in ("clt_spt_dense_adam", "clt_spt_dense_adam_multi"):  # gathered rows + read/write of the parameter, exp_avg and exp_avg_sq rows (per job)
         return es * (6 * M * d + N * k / world * d), "byte"
     if name == "clt_adam_step":
         return 7.0 * es * P_total, "byte"

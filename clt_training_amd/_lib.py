@@ -46,6 +46,13 @@ class RowsJob(C.Structure):
 
 CLT_ROWS_MAX_JOBS = 16
 
+
+class SptJob(C.Structure):
+    """clt_spt_job (include/clt_mi355.h)."""
+
+    _fields_ = [("perm", _vp), ("offsets", _vp), ("vals", _vp), ("vals_gate", _vp), ("dense", _vp), ("p", _vp), ("m", _vp),
+                ("v", _vp), ("rowsum", _vp)]
+
 # name -> (restype, argtypes); kept in the order of include/clt_mi355.h
 SIGNATURES = {
     "clt_version": (_i32, []),
@@ -77,6 +84,8 @@ SIGNATURES = {
     "clt_decode_bwd_rows_adam": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
                                         _i32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _i64, _vp, _sz, _vp]),
     "clt_rows_multi_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "clt_spt_dense_adam_multi": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _i64,
+                                        _vp, _sz, _vp]),
     "clt_decode_bwd_rows_adam_multi": (_i32, [_vp, _i32, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32,
                                               _i32, _i32, _i64, _vp, _sz, _vp]),
     "clt_rows_unit_norm": (_i32, [_vp, _i32, _i64, _i32, _f32, _vp]),

@@ -350,6 +350,56 @@ extern "C" int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, i
   return CLT_OK;
 }
 
+extern "C" int clt_spt_dense_adam_multi(const clt_spt_job* h_jobs, int n_jobs, int64_t M, int gate_dtype,
+                                        int dense_dtype, int d, int k, int p_dtype, float lr, float b1, float b2,
+                                        float eps, int step, int64_t n_entries, void* workspace,
+                                        size_t workspace_bytes, clt_stream_t stream) {
+  CLT_CHECK_ARG(h_jobs && n_jobs >= 1 && n_jobs <= CLT_ROWS_MAX_JOBS, "clt_spt_dense_adam_multi: 1..%d jobs",
+                CLT_ROWS_MAX_JOBS);
+  CLT_CHECK_ARG(M > 0 && M < (1ll << 31) && d > 0 && k > 0 && step >= 1 && valid_dtype(dense_dtype) &&
+                    valid_dtype(p_dtype), "clt_spt_dense_adam_multi: bad sizes / dtypes");
+  const int E = dense_dtype == CLT_BF16 ? 8 : 4;
+  int chunks = d / E, ch = (chunks + 63) / 64;
+  ch = ch <= 1 ? 1 : ch <= 2 ? 2 : ch <= 4 ? 4 : ch <= 8 ? 8 : -1;
+  const bool lds_ok = d % E == 0 && ch > 0 && dense_dtype == p_dtype && rows_lds_ok(d, dtype_size(p_dtype), ch);
+  RowsJobs jobs = {};
+  for (int i = 0; i < n_jobs; ++i) {
+    const clt_spt_job& h = h_jobs[i];
+    CLT_CHECK_ARG(h.perm && h.offsets && h.vals && h.dense && h.p && h.m && h.v && aligned16(h.dense) && aligned16(h.p) &&
+                      aligned16(h.m) && aligned16(h.v) && (!h.vals_gate || valid_dtype(gate_dtype)),
+                  "clt_spt_dense_adam_multi: job %d: null or misaligned pointer", i);
+    if (!lds_ok) {  // shapes the LDS-staged kernel does not take: one call per job
+      const int rc = clt_spt_dense_adam(h.perm, h.offsets, M, h.vals, h.vals_gate, gate_dtype, h.dense, dense_dtype, d, k,
+                                        h.p, h.m, h.v, p_dtype, h.rowsum, lr, b1, b2, eps, step, n_entries, workspace,
+                                        workspace_bytes, stream);
+      if (rc != CLT_OK) return rc;
+      continue;
+    }
+    RowsJob& jb = jobs.j[i];
+    jb.perm = h.perm;
+    jb.offsets = h.offsets;
+    jb.vals = h.vals;
+    jb.out = h.p;
+    jb.dense = h.dense;
+    jb.gate = h.vals_gate;
+    jb.rowsum = h.rowsum;
+    jb.ad = make_adam_rows(h.m, h.v, lr, b1, b2, eps, step);
+  }
+  if (!lds_ok) return CLT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = p_dtype == CLT_BF16
+                     ? launch_rows_lds_multi<bf16_t, false>(ch, st, jobs, n_jobs, M, nullptr, d, k, n_entries, workspace,
+                                                            workspace_bytes, gate_dtype)
+                     : launch_rows_lds_multi<float, false>(ch, st, jobs, n_jobs, M, nullptr, d, k, n_entries, workspace,
+                                                           workspace_bytes, gate_dtype);
+  if (rc != CLT_OK) {
+    set_error("clt_spt_dense_adam_multi: unsupported width");
+    return rc;
+  }
+  CLT_CHECK_LAUNCH("clt_spt_dense_adam_multi");
+  return CLT_OK;
+}
+
 extern "C" int clt_segment_sum(const int32_t* perm, const int32_t* offsets, int64_t M, const float* a, float* out_a,
                                const float* b, float* out_b, clt_stream_t stream) {
   CLT_CHECK_ARG(perm && offsets && a && out_a && (!b || out_b), "clt_segment_sum: null pointer");

@@ -566,6 +566,9 @@ struct RowsJob {
   const int32_t* offsets;
   const float* vals;
   void* out;  // ADAM: the parameter table
+  const void* dense;  // this job's dense rows, or null: the launch's common ones (the loss gradient of a target)
+  const void* gate;   // [n_entries] in the launch's gate dtype or null (encoder backward: the top-k values)
+  float* rowsum;      // [M] or null (encoder backward: grad b_enc)
   AdamRows ad;
   BwdActs bw;
   LongRows lr;
@@ -574,11 +577,12 @@ struct RowsJobs {
   RowsJob j[ROWS_MAX_JOBS];
 };
 
-template <typename T, int CH, int U>
+template <typename T, int CH, int U, bool BWD>
 __global__ __launch_bounds__(64) void rows_long_multi_kernel(const RowsJobs jobs, int64_t M, const T* __restrict__ dense,
-                                                             int d, int k) {
+                                                             int gate_dtype, int d, int k) {
   const RowsJob& jb = jobs.j[blockIdx.y];
-  rows_long_block<T, CH, U, true>(jb.perm, jb.offsets, M, jb.vals, nullptr, 0, dense, d, k, (const T*)jb.out, jb.bw, jb.lr);
+  rows_long_block<T, CH, U, BWD>(jb.perm, jb.offsets, M, jb.vals, jb.gate, gate_dtype,
+                                 jb.dense ? (const T*)jb.dense : dense, d, k, (const T*)jb.out, jb.bw, jb.lr);
 }
 
 // ADAM = false: the plain-gradient form (clt_spt_dense, clt_decode_bwd_rows): `out` receives the gradient row, only
@@ -791,12 +795,12 @@ __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds
   rows_lds_row<T, CH, U, BWD, ADAM>(perm, offsets, M, vals, gate, gate_dtype, dense, d, k, out, rowsum, ad, bw, lr);
 }
 
-template <typename T, int CH, int U>
+template <typename T, int CH, int U, bool BWD>
 __global__ __launch_bounds__(128, (CH <= 2 ? 4 : CH == 4 ? 3 : 1)) void rows_lds_multi_kernel(
-    const RowsJobs jobs, int64_t M, const T* __restrict__ dense, int d, int k) {
+    const RowsJobs jobs, int64_t M, const T* __restrict__ dense, int gate_dtype, int d, int k) {
   const RowsJob& jb = jobs.j[blockIdx.y];
-  rows_lds_row<T, CH, U, true, true>(jb.perm, jb.offsets, M, jb.vals, nullptr, 0, dense, d, k, (T*)jb.out,
-                                                        nullptr, jb.ad, jb.bw, jb.lr);
+  rows_lds_row<T, CH, U, BWD, true>(jb.perm, jb.offsets, M, jb.vals, jb.gate, gate_dtype,
+                                    jb.dense ? (const T*)jb.dense : dense, d, k, (T*)jb.out, jb.rowsum, jb.ad, jb.bw, jb.lr);
 }
 
 // The LDS-staged kernel serves rows of up to 10 KiB (2 waves * 3 arrays * row <= 64 KiB of LDS) and 8 chunks per lane.
@@ -838,9 +842,9 @@ static int launch_rows_lds(int ch, hipStream_t st, const int32_t* perm, const in
 
 // n_jobs decoder-backward + Adam row passes in one launch (plus one helper launch for their long segments); job i's
 // long-row partials take the i-th slice of the workspace
-template <typename T>
+template <typename T, bool BWD = true>
 static int launch_rows_lds_multi(int ch, hipStream_t st, RowsJobs& jobs, int n_jobs, int64_t M, const void* dense, int d,
-                                 int k, int64_t n_entries, void* workspace, size_t workspace_bytes) {
+                                 int k, int64_t n_entries, void* workspace, size_t workspace_bytes, int gate_dtype = 0) {
   const dim3 grid((unsigned)((M + 1) / 2), (unsigned)n_jobs);
   const size_t lds = 2 * (size_t)3 * (size_t)d * sizeof(T);
   const size_t per = (rows_long_workspace_bytes(n_entries, d) + 255) & ~(size_t)255;
@@ -854,8 +858,10 @@ static int launch_rows_lds_multi(int ch, hipStream_t st, RowsJobs& jobs, int n_j
 #define LAUNCH(CH, U)                                                                                              \
   do {                                                                                                             \
     if (longs)                                                                                                     \
-      hipLaunchKernelGGL((rows_long_multi_kernel<T, CH, U>), lgrid, dim3(64), 0, st, jobs, M, (const T*)dense, d, k); \
-    hipLaunchKernelGGL((rows_lds_multi_kernel<T, CH, U>), grid, dim3(128), lds, st, jobs, M, (const T*)dense, d, k); \
+      hipLaunchKernelGGL((rows_long_multi_kernel<T, CH, U, BWD>), lgrid, dim3(64), 0, st, jobs, M, (const T*)dense,   \
+                         gate_dtype, d, k);                                                                        \
+    hipLaunchKernelGGL((rows_lds_multi_kernel<T, CH, U, BWD>), grid, dim3(128), lds, st, jobs, M, (const T*)dense,   \
+                       gate_dtype, d, k);                                                                          \
   } while (0)
   switch (ch) {
     case 1: LAUNCH(1, 8); break;

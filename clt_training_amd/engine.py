@@ -821,6 +821,9 @@ class CLTEngine:
         last one (runner.py:56-59, 193-197; fused_encoder.py:92-155)."""
         ops = self.ops
         still = []
+        enc_jobs = []  # encoder row passes of the sources that finish now, batched into one launch when several do
+        fo = self.fused_opt
+        batch_enc = (fo is not None and acc_steps == 1 and ROUTES.rows_multi and hasattr(ops, "spt_dense_adam_multi"))
         for st in self.live:
             li = self.coders[st.layer]
             st.slot += 1
@@ -839,12 +842,31 @@ class CLTEngine:
                         lo = (gbe - hi.float()).to(li.W_enc.dtype)
                         sx = (torch.stack([hi, lo]) @ li.W_enc).float().sum(0, keepdim=True)
                     self._acc_grad(li.b_decs[0], -sx.view(-1).float())
+                h = fo.fused_rows(li.W_enc) if batch_enc and li.W_enc.grad is None else None
+                if h is not None:
+                    enc_jobs.append((li, h, dict(seg=st.seg, vals=st.gv.view(-1), dense=st.x_enc, p=li.W_enc.data, m=h["m"],
+                                                 v=h["v"], gate=st.v.contiguous().view(-1), want_rowsum=True)))
+                    continue
                 gb = self._grad_rows(li.W_enc, st.seg, st.gv.view(-1), st.x_enc, acc_steps,
                                      gate=st.v.contiguous().view(-1), want_rowsum=True)
                 self._acc_grad(li.b_enc, gb.to(li.b_enc.dtype))
             else:
                 still.append(st)
         self.live = still
+        if enc_jobs:
+            same = all(j[2]["p"].shape == enc_jobs[0][2]["p"].shape and j[2]["seg"].k == enc_jobs[0][2]["seg"].k
+                       and (j[1]["lr"], j[1]["betas"], j[1]["eps"]) == (enc_jobs[0][1]["lr"], enc_jobs[0][1]["betas"],
+                                                                        enc_jobs[0][1]["eps"]) for j in enc_jobs)
+            if len(enc_jobs) > 1 and same:
+                h0 = enc_jobs[0][1]
+                sums = ops.spt_dense_adam_multi([j[2] for j in enc_jobs], lr=h0["lr"], betas=h0["betas"], eps=h0["eps"],
+                                                step=h0["step"])
+            else:
+                sums = [ops.spt_dense_adam(j["seg"], j["vals"], j["dense"], j["p"], j["m"], j["v"], lr=h["lr"],
+                                           betas=h["betas"], eps=h["eps"], step=h["step"], gate=j["gate"], want_rowsum=True)
+                        for _, h, j in enc_jobs]
+            for (li, _, _), gb in zip(enc_jobs, sums):
+                self._acc_grad(li.b_enc, gb.to(li.b_enc.dtype))
 
     def _fused_state(self, p: Tensor, acc_steps: int):
         """Optimizer state / hyper-parameters for applying this step's update of ``p`` inside the gradient kernel, or

@@ -426,6 +426,47 @@ def spt_dense_adam(seg: Segments, vals: Tensor, dense: Tensor, p: Tensor, m: Ten
     return rowsum
 
 
+def spt_dense_adam_multi(jobs, *, lr: float, betas, eps: float, step: int):
+    """Several ``spt_dense_adam`` passes of one shape in ONE launch (clt_spt_dense_adam_multi).  ``jobs``: dicts with
+    seg, vals, dense, p, m, v, optionally gate, want_rowsum.  Returns the list of row sums (None where not asked);
+    bitwise the results of one spt_dense_adam call per job."""
+    j0 = jobs[0]
+    M, d = j0["p"].shape
+    n = j0["seg"].perm.numel()
+    gdt = None
+    tabs, outs, keep = [], [], []
+    for jb in jobs:
+        seg, p, m, v = jb["seg"], jb["p"], jb["m"], jb["v"]
+        vals, dense = _c(jb["vals"]), _c(jb["dense"])
+        gate = None if jb.get("gate") is None else _c(jb["gate"])
+        assert vals.dtype == torch.float32 and vals.numel() == seg.perm.numel() == n and seg.M == M and seg.k == j0["seg"].k
+        assert p.shape == (M, d) and dense.shape[1] == d and dense.dtype == _c(j0["dense"]).dtype and p.dtype == j0["p"].dtype
+        assert p.is_contiguous() and m.is_contiguous() and v.is_contiguous() and m.dtype == p.dtype == v.dtype
+        assert m.shape == p.shape == v.shape
+        if gate is not None:
+            assert gdt is None or gate.dtype == gdt
+            gdt = gate.dtype
+        rowsum = torch.empty(M, dtype=torch.float32, device=p.device) if jb.get("want_rowsum") else None
+        outs.append(rowsum)
+        tabs.append((seg.perm, seg.offsets, vals, gate, dense, p, m, v, rowsum))
+        keep.append((vals, dense, gate))
+    lib = _lib.load()
+    for c0 in range(0, len(tabs), _lib.CLT_ROWS_MAX_JOBS):
+        grp = tabs[c0:c0 + _lib.CLT_ROWS_MAX_JOBS]
+        tab = (_lib.SptJob * len(grp))()
+        for ent, fields in zip(tab, grp):
+            for (name, _), t in zip(_lib.SptJob._fields_, fields):
+                setattr(ent, name, _ptr(t))
+        ws = workspace(j0["p"].device, lib.clt_rows_multi_workspace_bytes(n, d, len(grp)), "rows_multi")
+        _call("clt_spt_dense_adam_multi", C.cast(tab, C.c_void_p), len(grp), M, _DT[gdt] if gdt is not None else 0,
+              _dt(keep[0][1]), d, j0["seg"].k, _dt(j0["p"]), float(lr), float(betas[0]), float(betas[1]), float(eps),
+              int(step), n, _ptr(ws), ws.numel(), _stream(j0["p"]))
+        if PROFILE is not None and PROFILE.active:
+            PROFILE.units["clt_spt_dense_adam_multi"] = PROFILE.units.get("clt_spt_dense_adam_multi", 0) + len(grp)
+    del keep
+    return outs
+
+
 def decode_bwd_rows(seg: Segments, acts: Tensor, v: Tensor, W: Tensor, G: Tensor, grad_acts: Tensor, *,
                     post_enc: Optional[Tensor] = None, post_scale: Optional[Tensor] = None, want_g_post: bool = False,
                     adam: Optional[dict] = None):

@@ -233,6 +233,25 @@ int clt_spt_dense_adam(const int32_t* perm, const int32_t* offsets, int64_t M, c
                        int p_dtype, float* rowsum, float lr, float b1, float b2, float eps, int step,
                        int64_t n_entries, void* workspace, size_t workspace_bytes, clt_stream_t stream);
 
+/* n_jobs clt_spt_dense_adam passes that share M, d, k, the dtypes and the Adam hyper-parameters as one launch (the
+ * encoder backward of every layer that finishes in the same hook call -- all of them at the last layer when
+ * cross_layer covers the model, runner.py:56-59, 193-197); bitwise the results of n_jobs separate calls.  h_jobs is a
+ * HOST array; workspace: clt_rows_multi_workspace_bytes(n_entries, d, n_jobs) or NULL.                       */
+typedef struct clt_spt_job {
+  const int32_t* perm;
+  const int32_t* offsets;
+  const float* vals;      /* [N*k] fp32 */
+  const void* vals_gate;  /* [N*k] gate_dtype or NULL */
+  const void* dense;      /* [N,d] dense_dtype: this layer's encoder input */
+  void* p;                /* [M,d] p_dtype, updated in place */
+  void* m;
+  void* v;
+  float* rowsum;          /* [M] or NULL */
+} clt_spt_job;
+int clt_spt_dense_adam_multi(const clt_spt_job* h_jobs, int n_jobs, int64_t M, int gate_dtype, int dense_dtype, int d,
+                             int k, int p_dtype, float lr, float b1, float b2, float eps, int step, int64_t n_entries,
+                             void* workspace, size_t workspace_bytes, clt_stream_t stream);
+
 /* Decoder backward of one (source, target) pair as ONE row pass: the weight gradient of clt_spt_dense (xformers.py:
  * 125-166), the gradient wrt the bag weights of clt_decode_bwd_acts (xformers.py:167-171) and the per-latent sums
  * of clt_segment_sum together.  For every decoder row r and every entry e = (n, j) of its segment:

@@ -863,3 +863,34 @@ def test_encode_topk_layers_equals_layer_by_layer(ops, L, N, M, d, k, bias):
         vr, ir = ops.encode_topk(xbuf[:, l * d:(l + 1) * d].contiguous(), Ws[l], bs[l] if bias else None, k)
         assert torch.equal(i[l], ir) and torch.equal(v[l], vr), l
     assert ops.encode_topk_layers(xbuf[:300].contiguous(), Ws, bs, k) is None  # N_l not a multiple of 2048
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_spt_dense_adam_multi_equals_one_call_per_job(ops, dtype):
+    """clt_spt_dense_adam_multi (the encoder backward of several layers in one launch) is bitwise one
+    clt_spt_dense_adam call per job: tables, both moments, row sums; different dense rows and gates per job, a long
+    segment in the first."""
+    N, d, M, k, n_jobs = 600, 256, 1024, 8, 3
+
+    def make():
+        g = torch.Generator().manual_seed(21)
+        jobs = []
+        for j in range(n_jobs):
+            idx = torch.stack([torch.randperm(M - 1, generator=g)[:k] + 1 for _ in range(N)])
+            if j == 0:
+                idx[:, 0] = 0  # one latent on every token: a long segment (N > 512)
+            jobs.append(dict(seg=ops.segments_build(idx.to(DEV), M), vals=torch.randn(N * k, generator=g).to(DEV),
+                             dense=torch.randn(N, d, generator=g).to(dtype).to(DEV),
+                             gate=(torch.randn(N * k, generator=g)).to(dtype).to(DEV), want_rowsum=True,
+                             p=(0.1 * torch.randn(M, d, generator=g)).to(dtype).to(DEV),
+                             m=(0.01 * torch.randn(M, d, generator=g)).to(dtype).to(DEV),
+                             v=(0.001 * torch.rand(M, d, generator=g)).to(dtype).to(DEV)))
+        return jobs
+
+    a, b = make(), make()
+    sums = ops.spt_dense_adam_multi(a, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, step=2)
+    for ja, jb, rs_a in zip(a, b, sums):
+        rs_b = ops.spt_dense_adam(jb["seg"], jb["vals"], jb["dense"], jb["p"], jb["m"], jb["v"], lr=1e-3, betas=(0.9, 0.999),
+                                  eps=1e-8, step=2, gate=jb["gate"], want_rowsum=True)
+        assert torch.equal(ja["p"], jb["p"]) and torch.equal(ja["m"], jb["m"]) and torch.equal(ja["v"], jb["v"])
+        assert torch.equal(rs_a, rs_b)

@@ -17,7 +17,8 @@ csv.field_size_limit(1 << 30)
 
 # kernel-name substring -> the C-ABI entry point (or stage of it) the launch belongs to
 RULES = [
-    ("rows_lds_multi_kernel", "", "clt_decode_bwd_rows_adam_multi"),
+    ("rows_lds_multi_kernel", "Lb1EEE", "clt_decode_bwd_rows_adam_multi"),
+    ("rows_lds_multi_kernel", "Lb0EEE", "clt_spt_dense_adam_multi"),
     ("rows_lds_kernel", "Lb1EEE", "clt_decode_bwd_rows_adam"),
     ("rows_lds_kernel", "Lb0EEE", "clt_spt_dense_adam"),
     ("decode_fwd_multi_kernel", "", "clt_decode_fwd_multi"),
