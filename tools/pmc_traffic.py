@@ -19,8 +19,8 @@ csv.field_size_limit(1 << 30)
 RULES = [
     ("rows_lds_multi_kernel", "Lb1EEE", "clt_decode_bwd_rows_adam_multi"),
     ("rows_lds_multi_kernel", "Lb0EEE", "clt_spt_dense_adam_multi"),
-    ("rows_lds_kernel", "Lb1EEE", "clt_decode_bwd_rows_adam"),
-    ("rows_lds_kernel", "Lb0EEE", "clt_spt_dense_adam"),
+    ("rows_lds_kernel", "Lb1ELb1EEE", "clt_decode_bwd_rows_adam"),  # <T, CH, U, BWD, ADAM>
+    ("rows_lds_kernel", "Lb0ELb1EEE", "clt_spt_dense_adam"),
     ("decode_fwd_multi_kernel", "", "clt_decode_fwd_multi"),
     ("decode_bwd_acts_multi_kernel", "", "clt_decode_bwd_acts_multi"),
     ("decode_fwd_kernel", "", "clt_decode_fwd"),
