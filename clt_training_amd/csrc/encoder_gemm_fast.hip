@@ -20,81 +20,12 @@
 // MFMA-bound: 2 * N * M * d flops per launch.
 #include <math.h>
 
-#include "gemm_fast.h"
+#include "gemm_fast_dev.h"
 #include "topk_select.h"
 
 namespace clt {
 namespace {
 
-__device__ uint4 g_zero16[1];  // 16 zero bytes: source for absent bias chunks
-
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-constexpr int ROWB = 64;                    // bytes of K per row per k-step (32 bf16)
-constexpr int OP_BYTES = GEMM_TM * ROWB;    // 16 KiB per operand per stage
-constexpr int NSTAGE = 4;
-constexpr int AUX_OFF = 2 * OP_BYTES;     // per stage and wave 768 B: [0, 256) bias of 64 latents, [256, 768) tau of 128 tokens
-constexpr int AUX_WAVE = 768;
-constexpr int STAGE_BYTES = 2 * OP_BYTES + 4 * AUX_WAVE;
-constexpr int NTHREADS = 256;
-constexpr int NDMA = 9;                     // LDS-DMAs per wave per stage: 4 W pieces, 4 x pieces, 1 bias/tau piece
-constexpr int QLANE = 10;                   // filter mode: 8-byte hit-queue entries per LANE and tile (5 KiB per wave)
-constexpr int NSTORE = 64;                  // store instructions per wave in the epilogue of an interior tile
-
-#define CLT_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-// LDS[m0 + 16 * lane] = *(sbase + voff): SGPR base, 32-bit lane offset.  Inline asm so that hipcc neither
-// counts nor drains it (see encoder_gemm.hip).
-__device__ __forceinline__ void dma_s(const char* sbase, uint32_t voff, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_dst)
-      : "memory");
-}
-__device__ __forceinline__ void dma_v(const char* src, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_dst)
-      : "memory");
-}
-
-__device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
-                                                 0);
-}
-
-// Accumulator element -> VGPR at the point of use.  Volatile asm, so hipcc cannot hoist the 256 reads of an
-// epilogue to its top (which needs 256 more VGPRs than there are and spills the loop-carried fragments).
-__device__ __forceinline__ float acc_read(float a) {
-  float r;
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(a));
-  return r;
-}
-
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Latent tiles can be a strided subset of W's 256-row tiles, so that one kernel serves the three launches of
-// the fused encode+top-k (gemm_fast.h): virtual tile v -> actual tile.
-__host__ __device__ __forceinline__ int lt_actual(int v, int mode, int S) {
-  if (mode == LT_SAMPLE) return v * S;                 // every S-th tile
-  if (mode == LT_REST) return v + v / (S - 1) + 1;     // all the others
-  return v;
-}
 
 // MODE 0: store relu(pre) (OT = bf16 or f32).  MODE 1: per-token threshold filter, no pre matrix (see FastArgs).
 template <typename OT, int MODE>
@@ -509,7 +440,7 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
                                                            const uint8_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ lists, int nL, int lt_S, int64_t N,
                                                            int64_t M, int k, int m, bf16_t* __restrict__ out_vals,
-                                                           int64_t* __restrict__ out_idx, int* __restrict__ flag) {
+                                                           int64_t* __restrict__ out_idx, int* __restrict__ flag, int l16) {
   constexpr int C = (R - S) * 64;
   __shared__ u64 lds_q[4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -534,6 +465,38 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
   bool over = false;
   const uint8_t* crow = counts + tok * nL;
   const uint32_t* lrow = lists + tok * (int64_t)nL * FUSED_SLOTS;
+  if (l16) {
+    // lists of the 16x16x32 kernel: l = ((virtual tile * 2 + wm) * 4 + lane quarter), 32 latents each, position
+    // pos = i * 4 + q.  A lane takes the four lists of one (tile, wm) -- their lengths are one aligned 32-bit load -- and
+    // walks their entries as one sequence, so an iteration offers up to 64 candidates out of 256 lists.
+    const uint32_t* crow4 = reinterpret_cast<const uint32_t*>(crow);  // nL % 8 == 0: rows are 8-byte aligned
+    const int nL4 = nL >> 2;
+    for (int g0 = 0; g0 < nL4; g0 += 64) {
+      const int g4 = g0 + lane;
+      const uint32_t cw = g4 < nL4 ? crow4[g4] : 0u;
+      int c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        c[u] = (int)((cw >> (8 * u)) & 255u);
+        if (c[u] > FUSED_SLOTS) over = true, c[u] = FUSED_SLOTS;
+      }
+      const int e1 = c[0], e2 = e1 + c[1], e3 = e2 + c[2], tot = e3 + c[3];
+      const unsigned lat_base = (unsigned)lt_actual(g4 >> 1, LT_REST, lt_S) * 256u + (g4 & 1) * 128;
+      for (int e = 0; __ballot(e < tot) != 0ull; ++e) {  // while some lane still has an entry
+        float v = -1.f;
+        unsigned col = 0;
+        if (e < tot) {
+          const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
+          const int ei = e - (u == 0 ? 0 : u == 1 ? e1 : u == 2 ? e2 : e3);
+          const uint32_t ent = lrow[((int64_t)g4 * 4 + u) * FUSED_SLOTS + ei];
+          v = __uint_as_float(ent & 0xffff0000u);
+          const unsigned pos = ent & 31u;
+          col = lat_base + 4 * u + (pos >> 2) * 16 + (pos & 3);
+        }
+        ws.offer(v >= ws.thr_val && v > 0.f, v, col);
+      }
+    }
+  } else
   for (int l0 = 0; l0 < nL; l0 += 64) {
     const int l = l0 + lane;
     int c = l < nL ? (int)crow[l] : 0;
@@ -591,6 +554,8 @@ static int grid_for(int64_t ntiles, int cus) { return (int)(ntiles < cus ? ntile
 int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_t st) {
   const int grid = grid_for((int64_t)a.nlt * a.ntt, cus);
   if (grid <= 0) return CLT_OK;
+  if (gemm_fast16_ok(a.M, a.kbytes) && !(a.dbg & 64))  // (-DCLT_TUNING builds: CLT_GEMM_DEBUG 64 = the 32x32x16 kernel)
+    return launch_gemm_fast16(a, out_dtype, filter, grid, st);
   if (filter)
     hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, 1>), dim3(grid), dim3(NTHREADS), 0, st, a);
   else if (out_dtype == CLT_BF16)
@@ -651,7 +616,10 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   pl.nltA = (int)nltA;
   pl.nltB = (int)nltB;
   pl.ntt = (int)ntt;
-  pl.nL = (int)nltB * 4;
+  pl.l16 = gemm_fast16_ok(M, d * 2) && !(tuning_env("CLT_GEMM_DEBUG", 0) & 64);
+  pl.nL = (int)nltB * (pl.l16 ? 8 : 4);
+  // the filter kernels address list entries with 32 bits
+  if ((int64_t)ntt * GEMM_TN * pl.nL * FUSED_SLOTS >= (1ll << 32)) return pl;
   pl.lds = nltA * GEMM_TM;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -724,13 +692,13 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   const dim3 grid((unsigned)((N + 3) / 4));
   if (k <= 64)
     hipLaunchKernelGGL((fused_select_kernel<1, 4>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag, pl.l16 ? 1 : 0);
   else if (k <= 128)
     hipLaunchKernelGGL((fused_select_kernel<2, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag, pl.l16 ? 1 : 0);
   else
     hipLaunchKernelGGL((fused_select_kernel<4, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag, pl.l16 ? 1 : 0);
   CLT_CHECK_LAUNCH("clt_encode_topk_fwd");
   // gated fallback (a list overflowed / a token failed verification): the flagged 256-token tiles the plain way, into
   // the same outputs.  The pre rows of those tiles land on the front of the workspace, over the lists (consumed by now).

@@ -8,7 +8,7 @@ namespace clt {
 constexpr int GEMM_TM = 256;   // latents per tile
 constexpr int GEMM_TN = 256;   // tokens per tile
 constexpr int GEMM_PANEL = 8;  // token tiles per L2 panel
-constexpr int FUSED_SLOTS = 8; // entries per candidate list (64 latents of one token)
+constexpr int FUSED_SLOTS = 8; // entries per candidate list (64 latents of one token; 32 with the 16x16x32 kernel)
 constexpr int GEMM_MAX_LAYERS = 16;
 
 enum { LT_ALL = 0, LT_SAMPLE = 1, LT_REST = 2 };
@@ -67,6 +67,10 @@ struct FastArgs {
 // true when the fast kernel takes this problem (bf16 operands, K rows a multiple of 64 bytes, M a multiple of 8)
 bool gemm_fast_supported(int in_dtype, int64_t N, int64_t M, int d);
 int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_t st);
+// The 16x16x32 build of the same kernel (encoder_gemm_fast16.hip) takes the shapes with K a multiple of 64 elements, at
+// least 128, and M a multiple of 16; launch_gemm_fast picks it by this predicate, so the launches of one call agree.
+bool gemm_fast16_ok(int64_t M, int kbytes);
+int launch_gemm_fast16(const FastArgs& a, int out_dtype, bool filter, int grid, hipStream_t st);
 
 // Fused encode + top-k without the pre-activation matrix:
 //   pass A  GEMM over every S-th latent tile, stored [N, lds], and clt_topk_rows over it: per token the best k of the
@@ -80,6 +84,7 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 //           [1 + ntt .. 1 + 2 ntt) the compacted tile ids.
 struct FusedPlan {
   bool ok;
+  bool l16;         // lists of 32 latents, 8 per latent tile (the 16x16x32 kernel); else 64 latents, 4 per tile
   int S, nltA, nltB, ntt, nL;
   int m;            // rank of the sample value that serves as threshold (<= k)
   int qflush;       // see FastArgs

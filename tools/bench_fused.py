@@ -48,8 +48,9 @@ def main():
     ap.add_argument("--rho", type=float, default=0.5)
     args = ap.parse_args()
     N, M, d, k = args.N, args.M, args.d, args.k
-    torch.manual_seed(0)
-    x = (torch.randn(N, d, device="cuda") + 0.1 * torch.randn(d, device="cuda")).bfloat16()
+    # (a seed of its own: with the dictionary's seed the first N rows of W would be the tokens themselves)
+    gx = torch.Generator(device="cuda").manual_seed(12345)
+    x = (torch.randn(N, d, device="cuda", generator=gx) + 0.1 * torch.randn(d, device="cuda", generator=gx)).bfloat16()
     for kind in args.kinds.split(","):
         W, b = dictionary(kind, M, d, args.rho)
         v, i = ops.encode_topk(x, W, b, k)
