@@ -629,6 +629,7 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   pl.off_tau = take((size_t)ntt * GEMM_TN * 4);
   pl.off_counts = take((size_t)N * pl.nL);
   pl.off_lists = take((size_t)N * pl.nL * FUSED_SLOTS * 4);
+  pl.off_xp = take(pl.l16 ? (size_t)ntt * GEMM_TN * d * 2 : 0);  // packed x (16x16x32 kernel)
   pl.bytes = off;
   pl.ok = true;
   return pl;
@@ -660,6 +661,11 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   if (hipMemsetAsync(flag, 0, (size_t)(1 + pl.ntt) * sizeof(int), st) != hipSuccess) {
     set_error("clt_encode_topk_fwd: hipMemsetAsync failed");
     return CLT_ERR_LAUNCH;
+  }
+  if (pl.l16) {  // pass A and pass B read x from a k-step-major copy (the rare fallback reads x in place)
+    launch_pack_x(a, ws + pl.off_xp, st);
+    a.xp = ws + pl.off_xp;
+    a.xp_kstep_bytes = (int64_t)pl.ntt * GEMM_TN * ROWB;
   }
   // pass A: every S-th latent tile, stored, and its row top-k -> the token thresholds
   FastArgs pa = a;
@@ -704,6 +710,7 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   // the same outputs.  The pre rows of those tiles land on the front of the workspace, over the lists (consumed by now).
   hipLaunchKernelGGL(fused_compact_kernel, dim3(1), dim3(64), 0, st, flag, pl.ntt);
   FastArgs pf = a;
+  pf.xp = nullptr;  // (its pre rows may land on the packed copy)
   pf.nlt = (int)((M + GEMM_TM - 1) / GEMM_TM);
   pf.lt_mode = LT_ALL;
   pf.pre = ws;

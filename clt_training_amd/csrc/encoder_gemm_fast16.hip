@@ -185,6 +185,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
   const unsigned long long aux_mask = __ballot(lane < nl || (MODE == 1 && lane >= 16 && lane < 48));
   const int ntt_layer = p.ntt_layer;
   const int ldx = ntt_layer ? (int)p.ldx_bytes : kbytes;  // bytes between consecutive token rows of x
+  const char* __restrict__ xp = p.xp;                      // packed copy of x (fused path), or null
+  const int64_t xstep = xp ? p.xp_kstep_bytes : ROWB;      // bytes from one k-step of x to the next
   constexpr int DMA_BIAS = 3 * 1024;  // piece q is loaded with immediate q * 1024: lane offsets carry + 3072 - q * 1024 >= 0
   auto loader_tile = [&](int lt, int tt) {
     const int64_t lat0 = (int64_t)lt_actual(lt, p.lt_mode, p.lt_S) * GEMM_TM, tok0 = (int64_t)tt * GEMM_TN;
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
     } else {
       ldX = xb + tok0 * kbytes - DMA_BIAS;
     }
+    if (xp) ldX = xp + tok0 * ROWB - DMA_BIAS;  // packed copy [k-step][token][64 B]: a piece is 1 KiB of consecutive bytes
     ldW = Wt + lat0 * kbytes - DMA_BIAS;
     // rows past the end re-read the last row (their products are never stored)
     const int maxW = (int)(M - 1 - lat0 < GEMM_TM ? M - 1 - lat0 : GEMM_TM);
@@ -207,7 +210,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
       const int r = (wave * 4 + q) * 16 + (lane >> 2);  // wave w stages rows 64 w .. 64 w + 63 of either operand
       const int c = (lane & 3) ^ ((0 - (r >> 2)) & 3);  // this kernel's bank swizzle (see the fragment addresses)
       voffW[q] = (uint32_t)((r < maxW ? r : maxW) * kbytes + c * 16 + DMA_BIAS - q * 1024);
-      voffX[q] = (uint32_t)((r < maxX ? r : maxX) * ldx + c * 16 + DMA_BIAS - q * 1024);
+      voffX[q] = xp ? (uint32_t)(r * ROWB + c * 16 + DMA_BIAS - q * 1024)  // (padding rows exist in the packed copy)
+                    : (uint32_t)((r < maxX ? r : maxX) * ldx + c * 16 + DMA_BIAS - q * 1024);
     }
     const int epc = 16 / bias_esize;
     const int64_t lat = lat0 + 64 * wave + lane * epc;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
     if constexpr (u == 0) set_m0(stage_lds + wave * 4096);
     else if constexpr (u <= 4) dma_m0<(u - 1) * 1024>(ldW + kb0, voffW[u - 1]);
     else if constexpr (u == 5) set_m0(stage_lds + OP_BYTES + wave * 4096);
-    else if constexpr (u <= 9) dma_m0<(u - 6) * 1024>(ldX + kb0, voffX[u - 6]);
+    else if constexpr (u <= 9) dma_m0<(u - 6) * 1024>(ldX + (int64_t)(kb0 / ROWB) * xstep, voffX[u - 6]);
     else if (kb0 == 0)  // a tile's first stage (wave-uniform): the tile's aux piece; lane l lands at + 16 l
       dma_aux(ldA, lds0 + AUX16_OFF + ((ld_t & 1) * 4 + wave) * AUX_WAVE, aux_mask);
   };
@@ -530,7 +534,30 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing fetches
 }
 
+// x[N, d] (row stride ldx bytes; stacked layers: FastArgs) -> xp[k-step][token][64 B], tokens padded to whole 256-token
+// tiles with copies of the last row.  A 16-row LDS-DMA piece of x is then 1 KiB of consecutive bytes instead of 16
+// segments of 64 B in 16 rows: the wave that issues it is held ~24 instead of ~42 cycles (tools/dma_cost.hip).
+__global__ void pack_x_kernel(const char* __restrict__ x, int64_t ldx, int64_t x_layer_bytes, int64_t N_l, int64_t N,
+                              int64_t Npad, int nsteps, uint4* __restrict__ xp) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= Npad * nsteps * 4) return;
+  const int c = (int)(g & 3);
+  const int64_t t = (g >> 2) % Npad, ks = (g >> 2) / Npad;
+  const int64_t tt = t < N ? t : N - 1;
+  const int64_t layer = N_l ? tt / N_l : 0, local = N_l ? tt - layer * N_l : tt;
+  xp[g] = *reinterpret_cast<const uint4*>(x + layer * x_layer_bytes + local * ldx + ks * ROWB + c * 16);
+}
+
 }  // namespace
+
+void launch_pack_x(const FastArgs& a, void* xp, hipStream_t st) {
+  const int64_t Npad = (int64_t)a.ntt * GEMM_TN;
+  const int nsteps = a.kbytes / ROWB;
+  const int64_t n = Npad * nsteps * 4;
+  hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.x,
+                     a.ntt_layer ? a.ldx_bytes : (int64_t)a.kbytes, a.x_layer_bytes,
+                     a.ntt_layer ? (int64_t)a.ntt_layer * GEMM_TN : (int64_t)0, a.N, Npad, nsteps, (uint4*)xp);
+}
 
 // K a multiple of 64 elements (the k loop is unrolled by two) and at least PF k-steps per tile (the loader, PF stages
 // ahead, is then never more than one tile ahead, which is what the two aux areas allow); M a multiple of 16.

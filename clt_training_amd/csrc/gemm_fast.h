@@ -59,6 +59,10 @@ struct FastArgs {
   int64_t ldx_bytes, x_layer_bytes;
   const char* Wl[GEMM_MAX_LAYERS];
   const char* biasl[GEMM_MAX_LAYERS];
+  // 16x16x32 kernel only: a packed copy of x, [k-step][token (padded to whole tiles)][64 B], from launch_pack_x; k-step s
+  // starts at xp + s * xp_kstep_bytes.  Null: x is read in place.
+  const char* xp;
+  int64_t xp_kstep_bytes;
   const int* gate;    // if set, the kernel returns at once unless *gate != 0 ...
   const int* tt_map;  // ... and, if tt_map is set too, *gate is the number of token tiles to do and tt_map[i] their ids
   int dbg;
@@ -71,6 +75,8 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 // least 128, and M a multiple of 16; launch_gemm_fast picks it by this predicate, so the launches of one call agree.
 bool gemm_fast16_ok(int64_t M, int kbytes);
 int launch_gemm_fast16(const FastArgs& a, int out_dtype, bool filter, int grid, hipStream_t st);
+// xp[a.kbytes / 64][a.ntt * 256][64 B] <- a.x (a.N, a.kbytes, a.ntt and the stacked-layer fields must be set)
+void launch_pack_x(const FastArgs& a, void* xp, hipStream_t st);
 
 // Fused encode + top-k without the pre-activation matrix:
 //   pass A  GEMM over every S-th latent tile, stored [N, lds], and clt_topk_rows over it: per token the best k of the
@@ -89,7 +95,7 @@ struct FusedPlan {
   int m;            // rank of the sample value that serves as threshold (<= k)
   int qflush;       // see FastArgs
   int64_t lds, Ls;  // sample matrix: leading dimension and valid columns
-  size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, bytes;
+  size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, off_xp, bytes;
 };
 FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k);
 // bytes of the flag area at the end of the clt_encode_topk_fwd workspace
