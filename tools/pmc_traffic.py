@@ -29,7 +29,8 @@ RULES = [
     ("fused_select_kernel", "", "fused_select_kernel"),
     ("topk_rows_kernel", "", "clt_topk_rows(sample)"),
     ("adam_kernel", "", "clt_adam_step"),
-    ("gemm_fast_kernel", "", "gemm_fast_kernel"),
+    ("pack_x_kernel", "", "pack_x_kernel"),
+    ("gemm_fast", "", "gemm_fast_kernel"),  # gemm_fast_kernel (32x32x16) and gemm_fast16_kernel (16x16x32)
 ]
 
 
@@ -71,7 +72,8 @@ def main():
             kernels[tag]["jobs_per_launch"] = JOBS[tag]
             kernels[tag]["hbm_bytes_per_job"] = kernels[tag]["hbm_bytes"] // JOBS[tag]
     # the fused encoder call = sample GEMM + sample top-k + filter GEMM + merge (its gated fallback launches fetch nothing)
-    stages = [k for k in kernels if k.startswith("gemm_fast_kernel") or k in ("clt_topk_rows(sample)", "fused_select_kernel")]
+    stages = [k for k in kernels if k.startswith("gemm_fast_kernel") or k in ("clt_topk_rows(sample)", "fused_select_kernel",
+                                                                          "pack_x_kernel")]
     if stages:
         kernels["clt_encode_topk_fwd"] = {"stages": stages, "hbm_bytes": sum(kernels[k]["hbm_bytes"] for k in stages)}
     doc = {"command": "rocprofv3 --pmc FETCH_SIZE (then, in a second run, --pmc WRITE_SIZE) --output-format csv -- python3 "
