@@ -99,7 +99,8 @@ int clt_candidates_unpack(const int64_t* packed, int64_t groups, int64_t rows, i
  * [N,M] in out_dtype + a 4 KiB tail that holds a device-side fallback flag.  bf16 operands with
  * M >= 320 k never form that matrix: the same bytes hold, laid over its front, the sample matrix
  * [N, M/S], the sample's top-k (values, int64 indices), the per-token thresholds tau[N], and the
- * candidate lists (8 x u32 per token and 64 latents) with their u8 lengths; the full matrix is written only
+ * candidate lists (8 x u32 per token and 64 latents -- per 32 latents where the 16x16x32 MFMA kernel runs: d % 64 == 0,
+ * d >= 128, M % 16 == 0, which also keeps a k-step-major copy of x there) with their u8 lengths; the full matrix is written only
  * by the device-gated fallback launches (a candidate list overflowed or a token failed verification).
  * Other dtypes / shapes: GEMM into the workspace, then clt_topk_rows over it.  Contents are scratch:
  * nothing in the workspace needs to survive the call, and calls sharing a workspace must be stream-ordered. */
