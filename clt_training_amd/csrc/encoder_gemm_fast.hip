@@ -575,7 +575,7 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   // list small.  An overflowing list costs only its 256-token tile's fallback (~1/ntt of a plain pass), so lists may run
   // at ~1 expected entry (P(> 8) ~ 1e-6 per list): S up to M / (40 k).  Latent shards (M / tp rows) therefore still take
   // the fused path: M = 12288, k = 32 -> S = 9 (was 2); M = 16384, k = 64 -> S = 6 (was unfused).
-  int64_t S = M / (40 * (int64_t)k);
+  int64_t S = M / (tuning_env("CLT_FUSED_SDIV", 40) * (int64_t)k);
   const int64_t s_cap = tuning_env("CLT_FUSED_SCAP", 16);  // -DCLT_TUNING builds only
   if (S > s_cap) S = s_cap;
   if (S < 2) return pl;

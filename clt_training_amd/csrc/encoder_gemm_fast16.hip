@@ -40,9 +40,10 @@ constexpr int STAGE16 = 2 * OP_BYTES;
 constexpr int AUX16_OFF = NSTAGE * STAGE16;
 constexpr int QUEUE16_OFF = AUX16_OFF + 2 * 4 * AUX_WAVE;
 constexpr int QLANE16 = 13;  // filter mode: 8-byte hit-queue entries per LANE between flushes (6.5 KiB per wave)
+constexpr int STG_WAVE = 16 * 256;  // store mode, bf16: a wave's staging area for one 16-token x 128-latent block
 constexpr int NDMA16 = 8;    // data LDS-DMAs per wave and stage (a tile's first stage has the aux piece on top)
 static_assert(QUEUE16_OFF + 4 * QLANE16 * 64 * 8 <= 160 * 1024, "LDS");
-static_assert(2 * NDMA16 == 16 && 2 * NDMA16 + NSTORE >= 63, "the counted waits of kstep assume these");
+static_assert(2 * NDMA16 == 16 && 2 * NDMA16 + NSTORE >= 63 && NSTORE == 64, "the counted waits of kstep assume these");
 
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -130,7 +131,7 @@ __device__ __forceinline__ void frag_wait(u32x4 (&A)[8], u32x4 (&B)[8]) {
 // MODE 0: store relu(pre) (OT = bf16 or f32).  MODE 1: per-token threshold filter, no pre matrix (see FastArgs).
 template <typename OT, int MODE>
 __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[QUEUE16_OFF + (MODE == 1 ? 4 * QLANE16 * 64 * 8 : 0)];
+  __shared__ __attribute__((aligned(1024))) char lds[QUEUE16_OFF + (MODE == 1 ? 4 * QLANE16 * 64 * 8 : sizeof(OT) == 2 ? 4 * STG_WAVE : 0)];
   int ntt = p.ntt;
   if (p.gate) {  // fallback launch: runs only if the fused path raised a flag
     const int flagged = *p.gate;
@@ -333,8 +334,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
 #elif defined(CLT_ABL16) && (CLT_ABL16 & 32)  // (ablation: no barrier)
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #else
-        if (after_stores) asm volatile("s_waitcnt vmcnt(63)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        if (after_stores) {  // 16 + the stores of an interior tile: 64 (f32: saturates at 63) or 32 (bf16, staged)
+          if constexpr (sizeof(OT) == 2) asm volatile("s_waitcnt vmcnt(48)\n\ts_barrier" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(63)\n\ts_barrier" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        }
 #endif
       }
       constexpr int q = dma_q_at(W, t), pc = read_at(W, t);
@@ -373,34 +378,60 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
       // M is a multiple of 16 (host), so a 16-latent MFMA tile is inside or outside M as a whole: wave-uniform tests
       const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);
       if constexpr (MODE == 0) {
-        // ---- store epilogue: ReLU, one rounding, 4 consecutive latents per store (16 tokens x 32 contiguous bytes per
-        //      instruction).  One code path for interior and edge tiles (two paths make hipcc hoist all 256 accumulator
-        //      reads above the branch: spills).
+        // ---- store epilogue: ReLU, one rounding.  bf16: each 16-token x 128-latent block goes through a wave-private
+        //      staging area in LDS (row = token, 256 B; 16-byte chunk c of row r at position c ^ r: the 8-byte writes of
+        //      a lane = (token, 4 latents) spread over all banks and the 16-byte reads of a lane = (token, 8 latents) are
+        //      conflict-free) and leaves as 16-byte stores, 4 tokens x 256 contiguous bytes per instruction: 32 store
+        //      instructions of 8 full lines per tile and wave instead of 64 of 16 x 32 bytes (a store is priced like an
+        //      LDS-DMA: by the lines it touches).  f32: 4 consecutive latents per 16-byte store, as before.  One code path
+        //      for interior and edge tiles (two paths make hipcc hoist all 256 accumulator reads above the branch: spills).
         if (!(dbg & 1)) {
           OT* pre = reinterpret_cast<OT*>(p.pre);
           const bool interior = tok0 + GEMM_TN <= N && lat_left == 128;
+          if constexpr (sizeof(OT) == 2) {
+            char* stg = lds + QUEUE16_OFF + wave * STG_WAVE;
+            const int rq = lane >> 4, cc = lane & 15;  // read side: row 4 r4 + rq of the block, 16-byte chunk cc
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int64_t tok = tok0 + wn * 128 + j * 16 + c16;
-            const bool tok_ok = tok < N;
-            OT* prow = pre + tok * p.ldp + (int64_t)cur_lt * GEMM_TM + wm * 128 + 4 * hq;
+            for (int j = 0; j < 8; ++j) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              if (tok_ok && i * 16 < lat_left) {
+              for (int i = 0; i < 8; ++i) {
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc_read(acc[i][j][q]), 0.f);
-                if constexpr (sizeof(OT) == 2) {
-                  uint2 u;
-                  u.x = pack_bf16x2(v[0], v[1]);
-                  u.y = pack_bf16x2(v[2], v[3]);
-                  *reinterpret_cast<uint2*>(prow + i * 16) = u;
-                } else {
+                uint2 u;
+                u.x = pack_bf16x2(v[0], v[1]);
+                u.y = pack_bf16x2(v[2], v[3]);
+                const int ch = 2 * i + (hq >> 1);  // 16-byte chunk of latents i * 16 + hq * 4 .. + 3 in the token's row
+                *reinterpret_cast<uint2*>(stg + c16 * 256 + ((ch ^ c16) & 15) * 16 + (hq & 1) * 8) = u;
+              }
+              CLT_FENCE();
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = r4 * 4 + rq;
+                const uint4 w = *reinterpret_cast<const uint4*>(stg + row * 256 + ((cc ^ row) & 15) * 16);
+                const int64_t tok = tok0 + wn * 128 + j * 16 + row;
+                if (tok < N && cc * 8 < lat_left)
+                  *reinterpret_cast<uint4*>(pre + tok * p.ldp + (int64_t)cur_lt * GEMM_TM + wm * 128 + cc * 8) = w;
+              }
+              CLT_FENCE();
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int64_t tok = tok0 + wn * 128 + j * 16 + c16;
+              const bool tok_ok = tok < N;
+              OT* prow = pre + tok * p.ldp + (int64_t)cur_lt * GEMM_TM + wm * 128 + 4 * hq;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                if (tok_ok && i * 16 < lat_left) {
+                  float v[4];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc_read(acc[i][j][q]), 0.f);
                   *reinterpret_cast<float4*>(prow + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
                 }
               }
+              CLT_FENCE();
             }
-            CLT_FENCE();
           }
           if (interior) stores_behind = 3;
         }

@@ -456,7 +456,8 @@ def test_topk_merge_explicit(ops):
 
 # --------------------------------------------------------------------------- encoder
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,M,d", [(128, 128, 64), (300, 520, 768), (77, 1000, 48), (1024, 4096, 256)])
+@pytest.mark.parametrize("N,M,d", [(128, 128, 64), (300, 520, 768), (77, 1000, 48), (1024, 4096, 256),
+                                   (2600, 2048, 128)])  # d = 128: four k-steps per tile, the 16x16x32 kernel's minimum
 def test_encoder_gemm_exact_integers(ops, dtype, N, M, d):
     """Small-integer operands: every product and partial sum is exact in fp32, so the MFMA
     result must equal the oracle bit for bit whatever the accumulation order."""
@@ -506,6 +507,7 @@ def _plain_encode_topk(ops, x, W, b, k):
     (8192, 98304, 768, 32, "f32"),      # BASELINE configs[1] layer shape: S = 16
     (1000, 20488, 128, 32, "bf16"),     # ragged token and latent edges (M % 256 = 8), S = 4
     (513, 12288, 768, 32, "f32"),       # a tensor-parallel shard of the above: S = 2
+    (5000, 16384, 128, 32, "bf16"),     # d = 128 (the 16x16x32 kernel's shortest k loop), several tiles per workgroup
     (300, 65536, 64, 64, None),         # k = 64, no bias
     (260, 90112, 96, 130, "f32"),       # k > 128: the widest selection state
 ])
