@@ -442,7 +442,9 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
                                                            int64_t M, int k, int m, bf16_t* __restrict__ out_vals,
                                                            int64_t* __restrict__ out_idx, int* __restrict__ flag, int l16) {
   constexpr int C = (R - S) * 64;
+  constexpr int NE_CAP = 512;  // non-empty list groups of a token that the 16x16x32 path keeps (2 KiB per wave)
   __shared__ u64 lds_q[4][C];
+  __shared__ uint32_t lds_ne[4][NE_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
   if (tok >= N) return;
@@ -467,34 +469,73 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
   const uint32_t* lrow = lists + tok * (int64_t)nL * FUSED_SLOTS;
   if (l16) {
     // lists of the 16x16x32 kernel: l = ((virtual tile * 2 + wm) * 4 + lane quarter), 32 latents each, position
-    // pos = i * 4 + q.  A lane takes the four lists of one (tile, wm) -- their lengths are one aligned 32-bit load -- and
-    // walks their entries as one sequence, so an iteration offers up to 64 candidates out of 256 lists.
-    const uint32_t* crow4 = reinterpret_cast<const uint32_t*>(crow);  // nL % 8 == 0: rows are 8-byte aligned
+    // pos = i * 4 + q; the four lists of one (tile, wm) = group g4 have their lengths in one aligned 32-bit word.
+    // Phase 1: the wave reads ALL its length words at once (16-byte loads issued back to back: one memory round trip
+    // instead of one per 64 lists) and compacts the non-empty groups, as (g4 << 16 | four 4-bit lengths), into LDS --
+    // about 150 of 720 at C2.  Phase 2: a lane takes one non-empty group per round and walks its entries; the first
+    // two entries' loads are issued before the first offer.  ~4 dependent round trips per token instead of ~24.
     const int nL4 = nL >> 2;
-    for (int g0 = 0; g0 < nL4; g0 += 64) {
-      const int g4 = g0 + lane;
-      const uint32_t cw = g4 < nL4 ? crow4[g4] : 0u;
-      int c[4];
+    const uint4* crow16 = reinterpret_cast<const uint4*>(crow);  // nL % 8 == 0 and nL * tok: rows are 8-byte aligned ...
+    const uint32_t* crow4 = reinterpret_cast<const uint32_t*>(crow);
+    volatile uint32_t* ne = lds_ne[wave];
+    int n_ne = 0;
+    const bool al16 = ((uintptr_t)crow & 15) == 0;  // ... 16-byte aligned when nL % 16 == 0 or the token is even
+    for (int w0 = 0; w0 < nL4; w0 += 256) {  // 64 lanes x 4 words per round
+      uint32_t cw[4];
+      const int wb = w0 + lane * 4;
+      if (al16 && wb + 4 <= nL4) {
+        const uint4 t = crow16[wb >> 2];
+        cw[0] = t.x, cw[1] = t.y, cw[2] = t.z, cw[3] = t.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cw[u] = wb + u < nL4 ? crow4[wb + u] : 0u;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        c[u] = (int)((cw >> (8 * u)) & 255u);
-        if (c[u] > FUSED_SLOTS) over = true, c[u] = FUSED_SLOTS;
+        uint32_t pk = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          uint32_t c = (cw[u] >> (8 * b)) & 255u;
+          if (c > (uint32_t)FUSED_SLOTS) over = true, c = FUSED_SLOTS;
+          pk |= c << (4 * b);
+        }
+        const bool nz = pk != 0u;
+        const unsigned long long bm = __ballot(nz);
+        const int pos = n_ne + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+        if (nz && pos < NE_CAP) ne[pos] = ((uint32_t)(wb + u) << 16) | pk;
+        n_ne += __popcll(bm);
       }
-      const int e1 = c[0], e2 = e1 + c[1], e3 = e2 + c[2], tot = e3 + c[3];
+    }
+    if (n_ne > NE_CAP) over = true, n_ne = NE_CAP;  // (hundreds of non-empty groups: the tile goes the plain way)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int r0 = 0; r0 < n_ne; r0 += 64) {
+      const uint32_t ent_ne = r0 + lane < n_ne ? ne[r0 + lane] : 0u;
+      const int g4 = (int)(ent_ne >> 16);
+      const int c0 = ent_ne & 15, c1 = (ent_ne >> 4) & 15, c2 = (ent_ne >> 8) & 15, c3 = (ent_ne >> 12) & 15;
+      const int e1 = c0, e2 = e1 + c1, e3 = e2 + c2, tot = e3 + c3;
       const unsigned lat_base = (unsigned)lt_actual(g4 >> 1, LT_REST, lt_S) * 256u + (g4 & 1) * 128;
-      for (int e = 0; __ballot(e < tot) != 0ull; ++e) {  // while some lane still has an entry
+      auto entry_addr = [&](int e) {
+        const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
+        const int ei = e - (u == 0 ? 0 : u == 1 ? e1 : u == 2 ? e2 : e3);
+        return ((int64_t)g4 * 4 + u) * FUSED_SLOTS + ei;
+      };
+      auto offer_entry = [&](int e, uint32_t ent) {
         float v = -1.f;
         unsigned col = 0;
         if (e < tot) {
           const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
-          const int ei = e - (u == 0 ? 0 : u == 1 ? e1 : u == 2 ? e2 : e3);
-          const uint32_t ent = lrow[((int64_t)g4 * 4 + u) * FUSED_SLOTS + ei];
           v = __uint_as_float(ent & 0xffff0000u);
           const unsigned pos = ent & 31u;
           col = lat_base + 4 * u + (pos >> 2) * 16 + (pos & 3);
         }
         ws.offer(v >= ws.thr_val && v > 0.f, v, col);
-      }
+      };
+      const uint32_t ent0 = 0 < tot ? lrow[entry_addr(0)] : 0u;
+      const uint32_t ent1 = 1 < tot ? lrow[entry_addr(1)] : 0u;
+      offer_entry(0, ent0);
+      if (__ballot(1 < tot) != 0ull) offer_entry(1, ent1);
+      for (int e = 2; __ballot(e < tot) != 0ull; ++e) offer_entry(e, e < tot ? lrow[entry_addr(e)] : 0u);
     }
   } else
   for (int l0 = 0; l0 < nL; l0 += 64) {
