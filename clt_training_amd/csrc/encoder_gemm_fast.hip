@@ -699,12 +699,15 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   a.ntt = pl.ntt;
   a.lt_S = pl.S;
   a.dbg = dbg;
-  if (hipMemsetAsync(flag, 0, (size_t)(1 + pl.ntt) * sizeof(int), st) != hipSuccess) {
+  // The flag area (gemm_fast.h) starts at zero; with the 16x16x32 kernel the x-packing launch clears it (one launch
+  // fewer: a memset costs ~5 us on a stream that has nothing else to run).  (Letting the merge kernel's last wave
+  // compact the flagged tile ids was tried too: a fence + one counter for 8192 waves took the kernel from 50 to 357 us.)
+  if (!pl.l16 && hipMemsetAsync(flag, 0, (size_t)(1 + pl.ntt) * sizeof(int), st) != hipSuccess) {
     set_error("clt_encode_topk_fwd: hipMemsetAsync failed");
     return CLT_ERR_LAUNCH;
   }
   if (pl.l16) {  // pass A and pass B read x from a k-step-major copy (the rare fallback reads x in place)
-    launch_pack_x(a, ws + pl.off_xp, st);
+    launch_pack_x(a, ws + pl.off_xp, flag, 1 + pl.ntt, st);
     a.xp = ws + pl.off_xp;
     a.xp_kstep_bytes = (int64_t)pl.ntt * GEMM_TN * ROWB;
   }

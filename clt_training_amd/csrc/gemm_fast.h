@@ -76,7 +76,8 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 bool gemm_fast16_ok(int64_t M, int kbytes);
 int launch_gemm_fast16(const FastArgs& a, int out_dtype, bool filter, int grid, hipStream_t st);
 // xp[a.kbytes / 64][a.ntt * 256][64 B] <- a.x (a.N, a.kbytes, a.ntt and the stacked-layer fields must be set)
-void launch_pack_x(const FastArgs& a, void* xp, hipStream_t st);
+// and zero_ints[0, n_zero) <- 0 (n_zero <= the launch's thread count)
+void launch_pack_x(const FastArgs& a, void* xp, int* zero_ints, int n_zero, hipStream_t st);
 
 // Fused encode + top-k without the pre-activation matrix:
 //   pass A  GEMM over every S-th latent tile, stored [N, lds], and clt_topk_rows over it: per token the best k of the
