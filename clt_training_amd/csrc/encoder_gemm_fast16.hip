@@ -164,15 +164,46 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
   const char* zero = reinterpret_cast<const char*>(g_zero16);
 
-  auto coords = [&](int id, int& lt, int& tt) {  // see tile_of (gemm_fast.h); lt is the VIRTUAL latent tile
-    const int full = nlt * GEMM_PANEL;
-    const int pp = id / full, rem = id - pp * full;
-    const int left = ntt - pp * GEMM_PANEL;
-    const int pt = left < GEMM_PANEL ? left : GEMM_PANEL;
-    lt = uni(rem / pt);
-    tt = uni(pp * GEMM_PANEL + rem % pt);
+  // Tile id -> (virtual latent tile, token tile), see tile_of (gemm_fast.h).  A workgroup's ids advance by nbx, so the
+  // position (panel pp, offset rem inside the panel) is carried along instead of divided out per tile: the two integer
+  // divisions of the straightforward form are ~150 scalar instructions between two k-steps, twice per tile (loader and
+  // multiplier), with the MFMA pipe idle.  Panels are GEMM_PANEL = 8 token tiles wide except the last one.
+  struct TilePos {
+    int pp, rem, pt, full;
+  };
+  auto pos_panel = [&](TilePos& c) {
+    const int left = ntt - c.pp * GEMM_PANEL;
+    c.pt = left < GEMM_PANEL ? left : GEMM_PANEL;
+    c.full = nlt * c.pt;
+  };
+  auto pos_init = [&](TilePos& c, int id) {
+    const int fullp = nlt * GEMM_PANEL;
+    c.pp = uni(id / fullp);
+    c.rem = uni(id - c.pp * fullp);
+    pos_panel(c);
+  };
+  auto pos_next = [&](TilePos& c) {
+    c.rem += nbx;
+    while (c.rem >= c.full) {
+      c.rem -= c.full;
+      ++c.pp;
+      pos_panel(c);
+    }
+  };
+  auto pos_get = [&](const TilePos& c, int& lt, int& tt) {
+    if (c.pt == GEMM_PANEL) {
+      lt = c.rem >> 3;
+      tt = c.pp * GEMM_PANEL + (c.rem & 7);
+    } else {
+      lt = uni(c.rem / c.pt);
+      tt = uni(c.pp * GEMM_PANEL + c.rem % c.pt);
+    }
     if (tt_map) tt = uni(tt_map[tt]);
   };
+  static_assert(GEMM_PANEL == 8, "pos_get shifts by 3");
+  TilePos ld_pos, cur_pos;
+  pos_init(ld_pos, xstart + bi);
+  cur_pos = ld_pos;
 
   // ---- loader state: runs PF stages ahead of the multiplier, possibly in the next tile.  Past the last stage it keeps
   //      re-fetching the last tile into ring slots nobody reads again, so that every k-step issues the same NDMA
@@ -237,7 +268,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
       ld_ks = 0;
       if (++ld_t < my_tiles) {
         int lt, tt;
-        coords(xstart + bi + ld_t * nbx, lt, tt);
+        pos_next(ld_pos);
+        pos_get(ld_pos, lt, tt);
         loader_tile(lt, tt);
       }
     }
@@ -297,7 +329,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
 
   // ---- prologue: PF stages in flight, all landed before the first MFMA (once per launch)
   int cur_lt, cur_tt;
-  coords(xstart + bi, cur_lt, cur_tt);
+  pos_get(cur_pos, cur_lt, cur_tt);
   loader_tile(cur_lt, cur_tt);
 #pragma unroll 1
   for (int pp = 0; pp < PF; ++pp) {
@@ -555,7 +587,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
       }
       ks = 0;
       if (++t_idx < my_tiles) {
-        coords(xstart + bi + t_idx * nbx, cur_lt, cur_tt);
+        pos_next(cur_pos);
+        pos_get(cur_pos, cur_lt, cur_tt);
         init_acc(t_idx & 1);  // its aux pieces came with stage s + 2, certified during the odd step
       }
     } else {
