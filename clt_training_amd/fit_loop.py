@@ -44,10 +44,13 @@ class FitLoop:
         return acts, widths, len(acts), model.device
 
     @staticmethod
-    def check_supported(cfg):
+    def check_supported(cfg, e2e_ok: bool = False):
         """Configurations the hot path does not implement fail loudly instead of training something else."""
-        if cfg.loss_fn != "fvu":  # trainer.py:739-780: the end-to-end losses run the SAE inside the model forward
-            raise NotImplementedError("only loss_fn='fvu' is on the MI355X hot path")
+        if cfg.loss_fn != "fvu" and not e2e_ok:  # trainer.py:739-780: the coders run inside the model's forward
+            raise NotImplementedError("loss_fn != 'fvu' (end-to-end losses) runs on trainer.Trainer with a model, "
+                                      "not on the latent-sharded engine")
+        if cfg.loss_fn not in ("fvu", "ce", "kl", "kl-fvu"):
+            raise ValueError(f"Unknown loss function '{cfg.loss_fn}'")
         if cfg.dead_latent_penalty > 0.0:  # trainer.py:653-676 (DeadLatentLoss)
             raise NotImplementedError("dead_latent_penalty > 0 (DeadLatentLoss) is not built")
         if len(cfg.init_seeds) != 1:  # (the reference's hook looks SAEs up by module name only, trainer.py:513-515, 544)

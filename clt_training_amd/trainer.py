@@ -19,12 +19,13 @@ from . import ckpt, fused_state
 from .adam import Adam
 from .config import TrainConfig
 from .engine import ROUTES
+from .e2e import EndToEnd, TokenBatches
 from .fit_loop import FitLoop, WarmupLinearSchedule  # noqa: F401 (re-exported)
 from .runner import CrossLayerRunner
 from .sparse_coder import SparseCoder
 
 
-class Trainer(FitLoop):
+class Trainer(EndToEnd, FitLoop):
     """``Trainer(cfg, dataset, model=None, mesh=None)``.
 
     With ``model=None``: ``cfg.hookpoints`` names the layers in network order; ``dataset`` is a sized iterable of
@@ -38,10 +39,18 @@ class Trainer(FitLoop):
                  input_widths: Optional[dict] = None, num_batches: Optional[int] = None):
         if mesh is not None:
             raise NotImplementedError("use clt_training_amd.tp for latent sharding over RCCL")
+        # loss_fn != "fvu" (trainer.py:739-785): the coders run inside the model's forward (e2e.EndToEnd); the dataset
+        # then stays a stream of token batches
+        e2e = cfg.loss_fn != "fvu"
+        if e2e and model is None:
+            raise ValueError("the end-to-end losses need the model: Trainer(cfg, token_dataset, model)")
         if model is not None:
+            tokens = dataset
             dataset, input_widths, num_batches, device = self.attach_model(cfg, dataset, model)
+            if e2e:
+                dataset = TokenBatches(tokens, cfg)
         assert cfg.hookpoints, "cached-activation training needs explicit cfg.hookpoints"
-        self.check_supported(cfg)
+        self.check_supported(cfg, e2e_ok=True)
         cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
         self.cfg = cfg
         self.dataset = dataset
@@ -82,7 +91,7 @@ class Trainer(FitLoop):
             [sae.num_latents for sae in self.saes.values()], num_batches)
         # Row gradients of the [M, d] matrices go straight into the Adam update inside the gradient kernels when each
         # optimizer step sees one micro-step (fused_state): no dense .grad, no second pass over the tables.
-        self._fused = (cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and ROUTES.fused_adam
+        self._fused = (cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and ROUTES.fused_adam and not e2e
                        and type(self.optimizers[0]) is Adam
                        # a decoder shared by several targets is read again after its first local backward
                        and not cfg.sae.per_source_tied)
@@ -152,6 +161,8 @@ class Trainer(FitLoop):
             fused_state.end_step()
 
     def _step(self, batch: dict, acc_steps: int):
+        if "input_ids" in batch:  # end-to-end losses: the hooks run inside the model's forward (e2e.EndToEnd)
+            return self._step_e2e(batch["input_ids"])
         self.runner.reset()
         loss_mask = batch.get("loss_mask")
         n_tok = 0
@@ -159,6 +170,10 @@ class Trainer(FitLoop):
             x, y = batch[name]
             n_tok = x.shape[0]
             self.hook(name, x, y, loss_mask, acc_steps)
+        return self._finish_step(n_tok)
+
+    def _finish_step(self, n_tok: int):
+        """Optimizer / scheduler / bookkeeping tail of a step (trainer.py:787-816, 858)."""
         self.num_tokens_in_step += n_tok
         step, substep = divmod(self.global_step + 1, self.cfg.grad_acc_steps)
         if substep == 0:

@@ -304,7 +304,8 @@ def golden_muon(name="muon_steps"):
                        ref="muon.py:13-42, 51-203 (ddp=False)"))
 
 
-def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3, warmup=2, optimizer="adam"):
+def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3, warmup=2, optimizer="adam",
+                   loss_fn="fvu"):
     """Drive the reference ``Trainer.fit`` (trainer.py:61-254, 376-865; mesh=None, optimizer="adam", FVU loss) on a
     random-init GPT-2 built from a config (no download) for ``steps`` batches, and record what pins SURVEY.md rows
     a18-a20, a22: the coders' parameters as constructed, after the data-dependent step-0 init (captured at the first
@@ -339,7 +340,7 @@ def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3,
                       # filter_bos=True skips `bos_mask &= 0` (trainer.py:687-688), which torch 2.10 rejects (Long into
                       # Bool); no token id equals bos_token_id here, so the mask is the same: first tokens only
                       filter_bos=True,
-                      log_to_wandb=False, save_dir=tmp, run_name="run", dead_feature_threshold=B * T)
+                      log_to_wandb=False, save_dir=tmp, run_name="run", dead_feature_threshold=B * T, loss_fn=loss_fn)
     tr = ref_tr.Trainer(cfg, ds, model)
     hooks = list(tr.saes)
     t = {}
@@ -425,10 +426,11 @@ def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3,
     for hd in handles:
         hd.remove()
     assert n_step[0] == steps
-    fit_acts = [a for a in acts if len(a) == L][-steps:]  # (resolve_widths ran the model once on dummy inputs)
-    for s, a in enumerate(fit_acts):
-        for l in range(L):
-            t[f"x{s}.{l}"], t[f"y{s}.{l}"] = a[l]
+    if loss_fn == "fvu":  # (the end-to-end losses run the model more than once per step, on changing activations)
+        fit_acts = [a for a in acts if len(a) == L][-steps:]  # (resolve_widths ran the model once on dummy inputs)
+        for s, a in enumerate(fit_acts):
+            for l in range(L):
+                t[f"x{s}.{l}"], t[f"y{s}.{l}"] = a[l]
     for l, h in enumerate(hooks):
         t[f"since_fired.{l}"] = tr.num_tokens_since_fired[h].clone()
     mask = torch.ones(B, T, dtype=torch.bool)
@@ -436,7 +438,7 @@ def golden_trainer(name, sae_kw, cross, b1, seed, L=3, d=32, T=16, B=2, steps=3,
     t["mask"] = mask.flatten()
     save(name, t, dict(cfg=sae_kw, L=L, d=d, cross_layer=cross, b1=b1, lr=1e-2, warmup=warmup, steps=steps,
                        tokens_per_step=B * T, hooks=hooks, seed=seed, num_batches=steps, optimizer=optimizer,
-                       dead_feature_threshold=B * T, checkpoint=ckpt_note,
+                       dead_feature_threshold=B * T, checkpoint=ckpt_note, loss_fn=loss_fn,
                        ref="trainer.py:61-254, 376-865 (fit, mesh=None)"))
     dst = OUT / f"{name}_ckpt"
     if dst.exists():
@@ -452,6 +454,17 @@ def main(only=None):
         golden_trainer("trainer_clt_b1_09", clt, cross=2, b1=0.9, seed=21)
         golden_trainer("trainer_clt_b1_00", dict(clt, normalize_io=True), cross=3, b1=0.0, seed=22)
         golden_trainer("trainer_sae_b1_09", dict(expansion_factor=8, k=4, transcode=False), cross=0, b1=0.9, seed=23)
+        return
+    if only == "e2e":  # end-to-end losses (trainer.py:739-785): the SAE output replaces the module output in the forward
+        clt = dict(expansion_factor=8, k=4, transcode=True, skip_connection=True)
+        if not (OUT / "trainer_clt_ce.safetensors").exists():
+            golden_trainer("trainer_clt_ce", clt, cross=2, b1=0.9, seed=31, loss_fn="ce")
+        if not (OUT / "trainer_clt_kl.safetensors").exists():
+            golden_trainer("trainer_clt_kl", dict(clt, post_encoder_scale=True), cross=3, b1=0.9, seed=32, loss_fn="kl")
+        # loss_fn="kl-fvu" cannot be driven with mesh=None: trainer.py:764-769 wraps kl in DTensor.from_local(kl, self.mesh,
+        # ...) unconditionally and torch raises "No device mesh is currently active!" (tried here) -- no golden for it.
+        golden_trainer("trainer_sae_kl", dict(expansion_factor=8, k=4, transcode=False), cross=0, b1=0.9, seed=34,
+                       loss_fn="kl")
         return
     if only == "muon":
         golden_muon()
