@@ -635,6 +635,177 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_multi_kernel(const SrcTab
   }
 }
 
+// clt_decode_fwd_multi with the gathered rows staged in LDS by LDS-DMA instead of landing in registers (bf16 tables, rows
+// of at most CH KiB).  MI355X_MICROARCH.md ('Indexed rows: gather into LDS') reads random rows faster through
+// global_load_lds_dwordx4 than through global_load_dwordx4 into registers; here every lane reads back exactly the bytes
+// it asked for (lane-linear landing: lane l's chunk of piece c sits at slot + c * 1024 + 16 l), so LDS is only a place
+// for loads in flight -- RS rows of CH KiB per wave, in two halves: the rows of batch b + 1 are requested before the
+// rows of batch b are consumed (counted vmcnt wait).  Same arithmetic, in the same order, as decode_fwd_multi_kernel.
+// rows in flight per wave: 4 waves * RS rows * (at most CH KiB) stays at or under 64 KiB a block, two blocks a CU (at
+// C2's 1536-byte rows 4 to 10 rows measured the same, 12 and 16 -- one block a CU -- 25 % slower)
+__host__ __device__ constexpr int lds_rows_per_wave(int pieces) { return pieces <= 2 ? 8 : pieces <= 4 ? 4 : 2; }
+
+__device__ __forceinline__ void lds_dma_row_piece(const char* src, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_dst)
+      : "memory");
+}
+
+template <typename OT, int CH>
+__global__ __launch_bounds__(256) void decode_fwd_multi_lds_kernel(const SrcTable tab, int ns, int v_dtype, int64_t M, int d,
+                                                                   const float* __restrict__ bias, OT* out, int flags,
+                                                                   int64_t N, int k) {
+  typedef bf16_t WT;
+  constexpr int E = Chunk<WT>::E;
+  constexpr int RS = lds_rows_per_wave(CH);
+  constexpr int H = RS / 2;  // rows per batch
+  __shared__ clt_decode_source lt[CLT_DECODE_MAX_SOURCES];
+  extern __shared__ __attribute__((aligned(1024))) char stage[];  // [4 waves][RS rows][SLOT = row bytes]
+  stage_table(tab, ns, lt);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  if (n >= N) return;  // wave-uniform, after the only barrier
+  const int nchunks = d / E;
+  const size_t row_bytes = (size_t)d * sizeof(WT);
+  const int SLOT = (int)row_bytes;  // piece c of a row lands at slot + c * 1024: the last piece is the short one
+  char* my = stage + (size_t)wave * RS * SLOT;
+  const uint32_t my_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)my;
+  float acc[CH][E];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[c][e] = 0.f;
+
+  const int total = ns * k;
+  for (int e0 = 0; e0 < total; e0 += 64) {
+    const int e = e0 + lane;
+    const bool active = e < total;
+    bool valid = false;
+    float my_a = 0.f;
+    unsigned my_lo = 0, my_hi = 0;
+    if (active) {
+      const int s = e / k, j = e - s * k;
+      const clt_decode_source& S = lt[s];
+      const int64_t o = n * k + j;
+      const int64_t rr = S.idx[o] - S.lat_begin;
+      valid = rr >= 0 && rr < M;
+      float a = 0.f;
+      if (valid) {
+        const float vv = load_scalar(S.v, v_dtype, o);
+        a = post_affine(vv, (int)rr, S.post_enc, S.post_scale);
+        if (flags & CLT_DECODE_ROUND_ACTS) a = bf16_bits_to_f32(f32_to_bf16_bits(a));
+        const uint64_t addr = reinterpret_cast<uint64_t>(S.W) + (uint64_t)rr * row_bytes;
+        my_lo = (unsigned)addr;
+        my_hi = (unsigned)(addr >> 32);
+      }
+      if (S.acts_out) S.acts_out[o] = a;
+      my_a = a * S.weight;
+    }
+    int cnt = min(64, total - e0);
+    if (__ballot(valid) != __ballot(active)) {
+      int nv;
+      const int dest = compact_dest(valid, active, nv);
+      my_lo = (unsigned)permute_push_i(dest, (int)my_lo);
+      my_hi = (unsigned)permute_push_i(dest, (int)my_hi);
+      my_a = permute_push_f(dest, my_a);
+      cnt = nv;
+    }
+    // (the scalar loads above are done: their results fed the address computation; the counted waits below see DMAs only)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto issue = [&](int jj0, int half) {
+#pragma unroll
+      for (int u = 0; u < H; ++u) {
+        const int jl = min(jj0 + u, cnt - 1);  // (rows past the end repeat the last one: every batch issues H * CH loads)
+        const uint64_t addr = ((uint64_t)(unsigned)readlane_i((int)my_hi, jl) << 32) | (unsigned)readlane_i((int)my_lo, jl);
+        const char* row = reinterpret_cast<const char*>(addr);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          // (lanes past the row's last chunk sit out; the wave still issues the instruction -- CH is the exact piece
+          // count, so every piece has at least one lane -- and a batch is H * CH loads for the counted wait)
+          if (ch < nchunks) lds_dma_row_piece(row + (size_t)ch * 16, my_lds + (uint32_t)((half * H + u) * SLOT + c * 1024));
+        }
+      }
+    };
+    if (cnt > 0) issue(0, 0);
+    int half = 0;
+    for (int jj = 0; jj < cnt; jj += H, half ^= 1) {
+      const bool more = jj + H < cnt;
+      if (more) {
+        issue(jj + H, half ^ 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(H * CH) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int u = 0; u < H; ++u) {
+        const float a_u = (jj + u < cnt) ? readlane_f(my_a, min(jj + u, cnt - 1)) : 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunks) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(my + (half * H + u) * SLOT + c * 1024 + lane * 16);
+            float w[E];
+            Chunk<WT>::expand(raw, w);
+#pragma unroll
+            for (int q = 0; q < E; ++q) acc[c][q] = fmaf(a_u, w[q], acc[c][q]);
+          }
+        }
+      }
+      // (the next batch's DMAs into this half are issued after these reads have returned: their data fed the FMAs)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+
+  OT* orow = out + n * (int64_t)d;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      if (bias) {
+        float b[E];
+        load_elems<float, E>(bias + ch * E, b);
+#pragma unroll
+        for (int q = 0; q < E; ++q) acc[c][q] += b[q];
+      }
+      if (flags & CLT_DECODE_ACCUMULATE) {
+        float o[E];
+        load_elems<OT, E>(orow + ch * E, o);
+#pragma unroll
+        for (int q = 0; q < E; ++q) acc[c][q] += o[q];
+      }
+      store_elems<OT, E>(orow + ch * E, acc[c]);
+    }
+  }
+}
+
+template <typename OT>
+static void launch_decode_fwd_multi_lds(int pieces, dim3 grid, hipStream_t st, const SrcTable& tab, int ns, int v_dtype,
+                                        int64_t M, int d, const float* bias, void* out, int flags, int64_t N, int k) {
+#define LAUNCH(CH)                                                                                                 \
+  hipLaunchKernelGGL((decode_fwd_multi_lds_kernel<OT, CH>), grid, dim3(256), (size_t)4 * lds_rows_per_wave(CH) * d * 2, \
+                     st, tab, ns, v_dtype, M, d, bias, (OT*)out, flags, N, k)
+  switch (pieces) {  // CH = the 1 KiB pieces of a row, exactly: every batch is H * CH loads for the counted wait
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    case 6: LAUNCH(6); break;
+    case 7: LAUNCH(7); break;
+    default: LAUNCH(8); break;
+  }
+#undef LAUNCH
+}
+
 static int check_sources(const char* name, const clt_decode_source* hs, int ns, bool bwd) {
   CLT_CHECK_ARG(hs && ns >= 1, "%s: no sources", name);
   CLT_UNSUPPORTED(ns <= CLT_DECODE_MAX_SOURCES, "%s: %d sources > CLT_DECODE_MAX_SOURCES", name, ns);
@@ -688,6 +859,18 @@ extern "C" int clt_decode_fwd_multi(const clt_decode_source* h_sources, int n_so
   for (int i = 0; i < n_sources; ++i) tab.s[i] = h_sources[i];
   dim3 grid((unsigned)((N + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
+  // bf16 tables with rows of at most 8 KiB: the LDS-staged gather (CLT_DECODE_LDS=0 in a -DCLT_TUNING build keeps the
+  // register gather below for A/B runs)
+  const int pieces = (d / E + 63) / 64;
+  if (w_dtype == CLT_BF16 && pieces <= 8 && (out_dtype == CLT_BF16 || out_dtype == CLT_F32) &&
+      tuning_env("CLT_DECODE_LDS", 1)) {
+    if (out_dtype == CLT_BF16)
+      launch_decode_fwd_multi_lds<bf16_t>(pieces, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
+    else
+      launch_decode_fwd_multi_lds<float>(pieces, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
+    CLT_CHECK_LAUNCH("clt_decode_fwd_multi");
+    return CLT_OK;
+  }
   if (w_dtype == CLT_BF16 && out_dtype == CLT_BF16)
     rc = launch_decode_fwd_multi<bf16_t, bf16_t>(ch, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
   else if (w_dtype == CLT_BF16 && out_dtype == CLT_F32)

@@ -89,10 +89,17 @@ def test_decode_fused_random(ops, dtype, N, d, M, k):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,d,M,k,ns,shard", [(130, 768, 2048, 32, 5, None), (67, 768, 1024, 32, 12, (256, 512)),
                                               (9, 2048, 512, 64, 3, None), (21, 104, 300, 70, 2, (100, 200)),
-                                              (5, 64, 128, 8, 19, (0, 64))])
+                                              (5, 64, 128, 8, 19, (0, 64)), (11, 1536, 400, 37, 3, None),
+                                              (7, 2304, 256, 9, 2, None), (10, 3072, 256, 21, 2, None),
+                                              (5, 3584, 200, 13, 2, None), (6, 4096, 300, 33, 3, (50, 250)),
+                                              (3, 8192, 64, 5, 2, None)])
 def test_decode_multi_source(ops, dtype, N, d, M, k, ns, shard):
     """clt_decode_fwd_multi / clt_decode_bwd_acts_multi == the per-source kernels summed (and the oracle); with a
-    latent shard, only the entries of rows [lo, hi) count.  ns = 19 exceeds CLT_DECODE_MAX_SOURCES (two launches)."""
+    latent shard, only the entries of rows [lo, hi) count.  ns = 19 exceeds CLT_DECODE_MAX_SOURCES (two launches).
+    The widths cover every piece count of the LDS-staged forward (bf16 rows of 1 .. 8 KiB, entry counts that leave a
+    short last batch) and one beyond it (d = 8192: the register gather)."""
+    if dtype == torch.float32 and d > 4096:
+        pytest.skip("fp32 rows wider than 16 KiB are refused (CLT_ERR_UNSUPPORTED)")
     g = torch.Generator().manual_seed(N * ns + d)
     lo, hi = shard or (0, M)
     Ml = hi - lo

@@ -21,7 +21,8 @@ RULES = [
     ("rows_lds_multi_kernel", "Lb0EEE", "clt_spt_dense_adam_multi"),
     ("rows_lds_kernel", "Lb1ELb1EEE", "clt_decode_bwd_rows_adam"),  # <T, CH, U, BWD, ADAM>
     ("rows_lds_kernel", "Lb0ELb1EEE", "clt_spt_dense_adam"),
-    ("decode_fwd_multi_kernel", "", "clt_decode_fwd_multi"),
+    ("decode_fwd_multi_lds_kernel", "", "clt_decode_fwd_multi"),
+    ("decode_fwd_multi_kernel", "", "clt_decode_fwd_multi(register gather)"),
     ("decode_bwd_acts_multi_kernel", "", "clt_decode_bwd_acts_multi"),
     ("decode_fwd_kernel", "", "clt_decode_fwd"),
     ("decode_bwd_acts_kernel", "", "clt_decode_bwd_acts"),
