@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
                                                            int64_t M, int k, int m, bf16_t* __restrict__ out_vals,
                                                            int64_t* __restrict__ out_idx, int* __restrict__ flag, int l16) {
   constexpr int C = (R - S) * 64;
-  constexpr int NE_CAP = 512;  // non-empty list groups of a token that the 16x16x32 path keeps (2 KiB per wave)
+  constexpr int NE_CAP = 512;  // non-empty list groups of a token held in LDS between two drains (2 KiB per wave)
   __shared__ u64 lds_q[4][C];
   __shared__ uint32_t lds_ne[4][NE_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -479,8 +479,46 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
     const uint32_t* crow4 = reinterpret_cast<const uint32_t*>(crow);
     volatile uint32_t* ne = lds_ne[wave];
     int n_ne = 0;
+    // phase 2 over the groups collected so far (called when the buffer could not take another round of 256 groups --
+    // a token with more than NE_CAP - 256 non-empty groups, e.g. k = 192 with ~500 candidates -- and at the end)
+    auto drain = [&]() {
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      for (int r0 = 0; r0 < n_ne; r0 += 64) {
+        const uint32_t ent_ne = r0 + lane < n_ne ? ne[r0 + lane] : 0u;
+        const int g4 = (int)(ent_ne >> 16);
+        const int c0 = ent_ne & 15, c1 = (ent_ne >> 4) & 15, c2 = (ent_ne >> 8) & 15, c3 = (ent_ne >> 12) & 15;
+        const int e1 = c0, e2 = e1 + c1, e3 = e2 + c2, tot = e3 + c3;
+        const unsigned lat_base = (unsigned)lt_actual(g4 >> 1, LT_REST, lt_S) * 256u + (g4 & 1) * 128;
+        auto entry_addr = [&](int e) {
+          const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
+          const int ei = e - (u == 0 ? 0 : u == 1 ? e1 : u == 2 ? e2 : e3);
+          return ((int64_t)g4 * 4 + u) * FUSED_SLOTS + ei;
+        };
+        auto offer_entry = [&](int e, uint32_t ent) {
+          float v = -1.f;
+          unsigned col = 0;
+          if (e < tot) {
+            const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
+            v = __uint_as_float(ent & 0xffff0000u);
+            const unsigned pos = ent & 31u;
+            col = lat_base + 4 * u + (pos >> 2) * 16 + (pos & 3);
+          }
+          ws.offer(v >= ws.thr_val && v > 0.f, v, col);
+        };
+        const uint32_t ent0 = 0 < tot ? lrow[entry_addr(0)] : 0u;
+        const uint32_t ent1 = 1 < tot ? lrow[entry_addr(1)] : 0u;
+        offer_entry(0, ent0);
+        if (__ballot(1 < tot) != 0ull) offer_entry(1, ent1);
+        for (int e = 2; __ballot(e < tot) != 0ull; ++e) offer_entry(e, e < tot ? lrow[entry_addr(e)] : 0u);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // (the LDS reads above are done before the next round overwrites the buffer)
+      __builtin_amdgcn_wave_barrier();
+      n_ne = 0;
+    };
     const bool al16 = ((uintptr_t)crow & 15) == 0;  // ... 16-byte aligned when nL % 16 == 0 or the token is even
     for (int w0 = 0; w0 < nL4; w0 += 256) {  // 64 lanes x 4 words per round
+      if (n_ne > NE_CAP - 256) drain();      // (wave-uniform: n_ne counts ballots)
       uint32_t cw[4];
       const int wb = w0 + lane * 4;
       if (al16 && wb + 4 <= nL4) {
@@ -502,41 +540,11 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
         const bool nz = pk != 0u;
         const unsigned long long bm = __ballot(nz);
         const int pos = n_ne + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
-        if (nz && pos < NE_CAP) ne[pos] = ((uint32_t)(wb + u) << 16) | pk;
+        if (nz) ne[pos] = ((uint32_t)(wb + u) << 16) | pk;  // pos < n_ne + 256 <= NE_CAP
         n_ne += __popcll(bm);
       }
     }
-    if (n_ne > NE_CAP) over = true, n_ne = NE_CAP;  // (hundreds of non-empty groups: the tile goes the plain way)
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    for (int r0 = 0; r0 < n_ne; r0 += 64) {
-      const uint32_t ent_ne = r0 + lane < n_ne ? ne[r0 + lane] : 0u;
-      const int g4 = (int)(ent_ne >> 16);
-      const int c0 = ent_ne & 15, c1 = (ent_ne >> 4) & 15, c2 = (ent_ne >> 8) & 15, c3 = (ent_ne >> 12) & 15;
-      const int e1 = c0, e2 = e1 + c1, e3 = e2 + c2, tot = e3 + c3;
-      const unsigned lat_base = (unsigned)lt_actual(g4 >> 1, LT_REST, lt_S) * 256u + (g4 & 1) * 128;
-      auto entry_addr = [&](int e) {
-        const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
-        const int ei = e - (u == 0 ? 0 : u == 1 ? e1 : u == 2 ? e2 : e3);
-        return ((int64_t)g4 * 4 + u) * FUSED_SLOTS + ei;
-      };
-      auto offer_entry = [&](int e, uint32_t ent) {
-        float v = -1.f;
-        unsigned col = 0;
-        if (e < tot) {
-          const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
-          v = __uint_as_float(ent & 0xffff0000u);
-          const unsigned pos = ent & 31u;
-          col = lat_base + 4 * u + (pos >> 2) * 16 + (pos & 3);
-        }
-        ws.offer(v >= ws.thr_val && v > 0.f, v, col);
-      };
-      const uint32_t ent0 = 0 < tot ? lrow[entry_addr(0)] : 0u;
-      const uint32_t ent1 = 1 < tot ? lrow[entry_addr(1)] : 0u;
-      offer_entry(0, ent0);
-      if (__ballot(1 < tot) != 0ull) offer_entry(1, ent1);
-      for (int e = 2; __ballot(e < tot) != 0ull; ++e) offer_entry(e, e < tot ? lrow[entry_addr(e)] : 0u);
-    }
+    drain();
   } else
   for (int l0 = 0; l0 < nL; l0 += 64) {
     const int l = l0 + lane;

@@ -590,7 +590,9 @@ def test_fused_encode_topk_fallback_is_per_token_tile(ops):
 
 @pytest.mark.parametrize("N,M,d,k", [(2048, 12288, 768, 32),    # C2 at tp8: the shard of 98304 latents
                                      (1024, 16384, 2048, 64),   # configs[2] (Llama-3.2-1B CLT) at tp8
-                                     (2048, 98304, 768, 32)])   # C2 unsharded
+                                     (2048, 98304, 768, 32),    # C2 unsharded
+                                     (512, 131072, 256, 192)])  # configs[3]'s latents and k (d cut to 256): ~500 candidates
+                                                                # per token in > 256 non-empty list groups for the merge
 def test_fused_encode_topk_stays_on_the_fused_path(ops, N, M, d, k):
     """A guard on BEHAVIOUR, not results (those are exact either way): on an ordinary dictionary the fused path must not
     send token tiles through the plain-GEMM fallback -- at latent-shard widths the candidate density per lane is ~5x the

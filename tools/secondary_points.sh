@@ -8,4 +8,4 @@ run n65536 --tokens 65536 &&
 run c3 --sae --layers 1 --d-model 4096 --expansion 32 --k 192 &&
 run c2slice --layers 6 --d-model 2048 --expansion 64 --k 64 &&
 run concat --coalesce concat &&
-run simtp8 --simulate-tp 8 --tokens 65536
+run simtp8 --simulate-tp 8
