@@ -294,6 +294,13 @@ static int pick_ch(int d, int E) {
 
 using namespace clt;
 
+namespace clt {
+// the LDS-staged fan-out kernel (below) when the problem fits it: bf16 table, rows of at most 8 KiB, bf16 / fp32 output.
+// Returns false without launching otherwise.
+static bool decode_fwd_lds_route(const clt_decode_source* hs, int ns, int v_dtype, int w_dtype, int64_t M, int d,
+                                 const float* bias, void* out, int out_dtype, int flags, int64_t N, int k, hipStream_t st);
+}  // namespace clt
+
 template <typename WT, typename OT>
 static int launch_decode_fwd(int ch, dim3 grid, hipStream_t st, const int64_t* idx, const void* v, int v_dtype,
                              const float* pe, const float* ps, const void* W, int64_t M, int64_t lat_begin, int d,
@@ -330,6 +337,15 @@ extern "C" int clt_decode_fwd(const int64_t* idx, const void* v, int v_dtype, co
   if (N == 0) return CLT_OK;
   dim3 grid((unsigned)((N + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
+  {  // one source of the fan-out kernel (weight 1: the same products and the same summation order)
+    clt_decode_source one = {};
+    one.idx = idx, one.v = v, one.post_enc = post_enc, one.post_scale = post_scale, one.W = W, one.acts_out = acts_out;
+    one.lat_begin = lat_begin, one.weight = 1.f;
+    if (decode_fwd_lds_route(&one, 1, v_dtype, w_dtype, M, d, bias, out, out_dtype, flags, N, k, st)) {
+      CLT_CHECK_LAUNCH("clt_decode_fwd");
+      return CLT_OK;
+    }
+  }
   int rc;
   if (w_dtype == CLT_BF16 && out_dtype == CLT_BF16)
     rc = launch_decode_fwd<bf16_t, bf16_t>(ch, grid, st, idx, v, v_dtype, post_enc, post_scale, W, M, lat_begin, d, bias, out, flags, acts_out, N, k);
@@ -806,6 +822,23 @@ static void launch_decode_fwd_multi_lds(int pieces, dim3 grid, hipStream_t st, c
 #undef LAUNCH
 }
 
+static bool decode_fwd_lds_route(const clt_decode_source* hs, int ns, int v_dtype, int w_dtype, int64_t M, int d,
+                                 const float* bias, void* out, int out_dtype, int flags, int64_t N, int k, hipStream_t st) {
+  const int pieces = (d / 8 + 63) / 64;
+  // (CLT_DECODE_LDS=0 in a -DCLT_TUNING build keeps the register gathers for A/B runs)
+  if (w_dtype != CLT_BF16 || d % 8 != 0 || pieces > 8 || (out_dtype != CLT_BF16 && out_dtype != CLT_F32) ||
+      !tuning_env("CLT_DECODE_LDS", 1))
+    return false;
+  SrcTable tab = {};
+  for (int i = 0; i < ns; ++i) tab.s[i] = hs[i];
+  const dim3 grid((unsigned)((N + 3) / 4));
+  if (out_dtype == CLT_BF16)
+    launch_decode_fwd_multi_lds<bf16_t>(pieces, grid, st, tab, ns, v_dtype, M, d, bias, out, flags, N, k);
+  else
+    launch_decode_fwd_multi_lds<float>(pieces, grid, st, tab, ns, v_dtype, M, d, bias, out, flags, N, k);
+  return true;
+}
+
 static int check_sources(const char* name, const clt_decode_source* hs, int ns, bool bwd) {
   CLT_CHECK_ARG(hs && ns >= 1, "%s: no sources", name);
   CLT_UNSUPPORTED(ns <= CLT_DECODE_MAX_SOURCES, "%s: %d sources > CLT_DECODE_MAX_SOURCES", name, ns);
@@ -859,15 +892,7 @@ extern "C" int clt_decode_fwd_multi(const clt_decode_source* h_sources, int n_so
   for (int i = 0; i < n_sources; ++i) tab.s[i] = h_sources[i];
   dim3 grid((unsigned)((N + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
-  // bf16 tables with rows of at most 8 KiB: the LDS-staged gather (CLT_DECODE_LDS=0 in a -DCLT_TUNING build keeps the
-  // register gather below for A/B runs)
-  const int pieces = (d / E + 63) / 64;
-  if (w_dtype == CLT_BF16 && pieces <= 8 && (out_dtype == CLT_BF16 || out_dtype == CLT_F32) &&
-      tuning_env("CLT_DECODE_LDS", 1)) {
-    if (out_dtype == CLT_BF16)
-      launch_decode_fwd_multi_lds<bf16_t>(pieces, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
-    else
-      launch_decode_fwd_multi_lds<float>(pieces, grid, st, tab, n_sources, v_dtype, M, d, bias, out, flags, N, k);
+  if (decode_fwd_lds_route(h_sources, n_sources, v_dtype, w_dtype, M, d, bias, out, out_dtype, flags, N, k, st)) {
     CLT_CHECK_LAUNCH("clt_decode_fwd_multi");
     return CLT_OK;
   }
