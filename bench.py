@@ -327,7 +327,11 @@ def main():
             # HBM bytes per launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs at these
             # layer shapes; counters cannot be read from inside this process)
             traffic = None
-            pmcs = sorted((ROOT / "profiles").glob("r*_pmc_traffic*.json"))  # the newest pass (tools/pmc_traffic.py)
+            def _ver(path):  # rNN_pmc_traffic[_vK].json -> (NN, K): the newest pass (tools/pmc_traffic.py)
+                import re
+                m = re.match(r"r(\d+)_pmc_traffic(?:_v(\d+))?\.json$", path.name)
+                return (int(m.group(1)), int(m.group(2) or 0)) if m else (-1, 0)
+            pmcs = sorted((ROOT / "profiles").glob("r*_pmc_traffic*.json"), key=_ver)
             if pmcs and world == 1 and (N, d, M, k, es) == (8192, 768, 98304, 32, 2):
                 pk = json.loads(pmcs[-1].read_text())["kernels"]
                 traffic = pk.get(dominant, {}).get("hbm_bytes")
