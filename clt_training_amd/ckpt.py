@@ -80,6 +80,10 @@ def from_file_layout(blob: dict):
     if step is None:  # a reference-written file: torch.optim.Adam keeps one step tensor per parameter
         steps = [int(st["step"]) for st in nested.get("state", {}).values() if "step" in st]
         step = max(steps) if steps else None
+    # flatten_state keeps leaves only, so an EMPTY state (SignSGD keeps none; Adam before its first step) leaves no
+    # "state" key behind in the file: Optimizer.load_state_dict needs it
+    nested.setdefault("state", {})
+    nested.setdefault("param_groups", [])
     for g in nested.get("param_groups", []):
         if isinstance(g.get("betas"), list):
             g["betas"] = tuple(g["betas"])

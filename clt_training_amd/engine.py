@@ -50,7 +50,6 @@ class Routes:
     fused_adam: bool = True  # Adam applied inside the gradient kernels
     overlap: bool = True     # tp > 1: encoder half of layer j + 1 on a side stream
     overlap_single: bool = False  # the same at world 1 (no collectives to hide; measured)
-    graph: bool = True       # capture the step in a HIP graph where the trainer supports it
     pack: bool = True        # per-step packing of the skip matrices / decoder biases of all (source, target) pairs
     rows_multi: bool = True  # the row passes of all live sources of a target in one launch (clt_decode_bwd_rows_adam_multi)
     # world 1: the encoders of all layers in one set of launches (clt_encode_topk_fwd_layers).  Built, bit-identical,
@@ -722,8 +721,15 @@ class CLTEngine:
                 if ps is not None and ps.requires_grad:
                     self._acc_grad(ps, gs)
                 self._acc_grad(li.post_encs[t], gp)
-        if jobs:
-            for jb, (gp, gs) in zip(jobs, ops.decode_bwd_rows_adam_multi(jobs, G)):
+        # one launch per optimizer setting: every source is a parameter group of its own (its lr may differ, and a
+        # resumed run restores it per group), and a launch carries ONE set of Adam hyper-parameters
+        by_group: dict = {}
+        for jb in jobs:
+            ad = jb["adam"]
+            key = (float(ad["lr"]), tuple(ad["betas"]), float(ad["eps"]), int(ad["step"]), bool(ad.get("project", False)))
+            by_group.setdefault(key, []).append(jb)
+        for grp in by_group.values():
+            for jb, (gp, gs) in zip(grp, ops.decode_bwd_rows_adam_multi(grp, G)):
                 if jb["_ps"] is not None:
                     self._acc_grad(jb["_ps"], gs)
                 if jb["_pe"] is not None:

@@ -101,7 +101,9 @@ class FitLoop:
         num_latents = next(iter(self.saes.values())).num_latents
         self.initial_k = min(num_latents, self.cfg.sae.k * self.cfg.k_anneal_mul)  # trainer.py:263-265
         self.final_k = self.cfg.sae.k
-        self.best_loss = {name: float("inf") for name in self.cfg.hookpoints}
+        # trainer.py:267-271: one running best per hookpoint for the local loss, ONE scalar for the end-to-end losses
+        self.best_loss = ({name: float("inf") for name in self.cfg.hookpoints} if self.cfg.loss_fn == "fvu"
+                          else float("inf"))
 
     def get_current_k(self) -> int:
         """trainer.py:356-362: linear decay from ``initial_k`` to ``final_k`` over ``k_decay_steps``."""
@@ -157,42 +159,75 @@ class FitLoop:
             if hasattr(dataset, "skip"):
                 dataset = dataset.skip(self.global_step)
             elif hasattr(dataset, "__getitem__") and hasattr(dataset, "__len__"):
-                dataset = [dataset[i] for i in range(self.global_step, len(dataset))]
+                src, first = dataset, self.global_step  # lazy, like the reference's select(range(...)): nothing is
+                dataset = (src[i] for i in range(first, len(src)))  # loaded before its step
             else:
                 import itertools
 
                 dataset = itertools.islice(iter(dataset), self.global_step, None)  # plain iterables of step dicts
         denom = cfg.grad_acc_steps * cfg.micro_acc_steps * cfg.wandb_log_frequency
         avg_fvu = {}
+        avg_e2e = {}  # "ce" | "kl" + "acc_top1": the end-to-end losses' running means (trainer.py:448-450, 744, 777-778)
+        e2e_key = {"ce": "ce", "kl": "kl", "kl-fvu": "kl"}.get(cfg.loss_fn)
+
+        def running_loss():  # what save_best ranks by (trainer.py:451-455, 746, 779, 783)
+            if e2e_key is None:
+                return {n: float(v) for n, v in avg_fvu.items()}
+            return float(avg_e2e[e2e_key]) if e2e_key in avg_e2e else None
+
+        avg_losses = None
         for batch in dataset:
             fvus = self.step(batch)
             for name, f in fvus.items():  # stays on the device: no host sync per hook (the reference's float(), :648)
                 avg_fvu[name] = avg_fvu.get(name, 0.0) + f.detach() / denom
+            if e2e_key is not None:
+                for key, v in (getattr(self, "last_e2e", None) or {}).items():
+                    avg_e2e[key] = avg_e2e.get(key, 0.0) + v.detach() / denom
             step, substep = divmod(self.global_step, cfg.grad_acc_steps)  # step() has advanced global_step (:791, 858)
             if substep == 0:
-                if (step + 1) % cfg.save_every == 0:  # trainer.py:818-823
+                saving = (step + 1) % cfg.save_every == 0
+                if cfg.save_best and saving:
+                    avg_losses = running_loss()  # (a host sync: only on the steps that use it)
+                if saving:  # trainer.py:818-823
                     self.save()
-                    if cfg.save_best:
-                        self.save_best({n: float(v) for n, v in avg_fvu.items()})
+                    if cfg.save_best and avg_losses is not None:
+                        self.save_best(avg_losses)
                 if do_log and (step + 1) % cfg.wandb_log_frequency == 0:
                     info = {}  # trainer.py:829-851
+                    if cfg.loss_fn == "ce":
+                        info["ce_loss"] = float(avg_e2e.get("ce", 0.0))
+                    elif e2e_key == "kl":
+                        info["kl_loss"] = float(avg_e2e.get("kl", 0.0))
+                        info["acc_top1"] = float(avg_e2e.get("acc_top1", 0.0))
                     for name in self.saes:
                         info[f"dead_pct/{name}"] = self._dead_fraction(name)  # collective under tp: every rank calls
-                        info[f"fvu/{name}"] = float(avg_fvu[name])
+                        if "fvu" in cfg.loss_fn:  # (:844-845: "fvu" and "kl-fvu")
+                            info[f"fvu/{name}"] = float(avg_fvu[name])
                     info["k"] = self.get_current_k()
                     if self.wandb_log is not None:
                         self.wandb_log(info, step)
+                if cfg.save_best and not saving:
+                    avg_losses = running_loss()  # the reference's avg_losses keeps the last batch's running value
                 avg_fvu.clear()
+                avg_e2e.clear()
             if log is not None:
                 log(self.global_step, fvus)
         self.save()  # trainer.py:861
-        if cfg.save_best and avg_fvu:  # trainer.py:862-863
-            self.save_best({n: float(v) for n, v in avg_fvu.items()})
+        if cfg.save_best:  # trainer.py:862-863
+            if avg_fvu or avg_e2e:
+                avg_losses = running_loss()
+            if avg_losses is not None and avg_losses != {}:
+                self.save_best(avg_losses)
         return self
 
     def save_best(self, avg_loss: dict):
         """trainer.py:972-993: one checkpoint per hookpoint whose running loss is the lowest so far."""
         base = f"{self.default_path()}/best"
+        if not isinstance(avg_loss, dict):  # the end-to-end losses: one scalar, all coders under best/ (:984-989)
+            if avg_loss < self.best_loss:
+                self.best_loss = avg_loss
+                self.save(base)
+            return
         for name in self.saes:
             if avg_loss.get(name, float("inf")) < self.best_loss[name]:
                 self.best_loss[name] = avg_loss[name]

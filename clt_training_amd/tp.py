@@ -179,7 +179,9 @@ class TPTrainer(FitLoop):
         gathered to rank 0), ``lr_scheduler_0.pt``, ``state.pt`` (global_step) and ``rank_{r}_state.pt``
         (num_tokens_since_fired, best_loss) as the reference writes them, and ``optimizer_0.pt``: the shards of every
         state tensor gathered to rank 0 and flattened exactly as the reference does (utils.py:193-277, 280-360), so the
-        checkpoint resumes on any tp degree, here or in the reference."""
+        checkpoint resumes on any tp degree, here or in the reference.  EXCEPTION: ``optimizer="muon"`` writes per-rank
+        ``optimizer_{i}.rank{r}.pt`` files (shard-local momentum) and resumes on the same tp degree only -- neither a
+        reference-written nor a ``Trainer``-written Muon checkpoint loads here (load_state says so)."""
         from pathlib import Path
 
         path = Path(path or self.default_path())
@@ -211,7 +213,8 @@ class TPTrainer(FitLoop):
             dist.barrier(group=self.comm.group)
 
     def load_state(self, path):
-        """Resume from ``save(path)`` -- or from a checkpoint the reference wrote -- on any tp degree."""
+        """Resume from ``save(path)`` -- or from a checkpoint the reference wrote -- on any tp degree (Muon: from this
+        class's own per-rank files at the same tp degree only)."""
         from pathlib import Path
 
         path = Path(path)
@@ -224,6 +227,11 @@ class TPTrainer(FitLoop):
                 for (_, b), (_, c) in zip(sae.named_buffers(), loaded.named_buffers()):
                     b.copy_(c)
         if self.cfg.optimizer == "muon":
+            if not (path / f"optimizer_0.rank{rank}.pt").exists():
+                raise FileNotFoundError(
+                    f"{path}: no optimizer_0.rank{rank}.pt -- a Muon checkpoint resumes under TPTrainer only from "
+                    "TPTrainer.save() at the same tp degree (the reference / Trainer layout optimizer_{0,1}.pt is not "
+                    "re-sharded for Muon)")
             for i, opt in enumerate(self.optimizers):
                 opt.load_state_dict(torch.load(path / f"optimizer_{i}.rank{rank}.pt", map_location=self.device,
                                                weights_only=True))
@@ -235,9 +243,11 @@ class TPTrainer(FitLoop):
         fired = torch.load(path / f"rank_{rank}_state.pt", map_location=self.device, weights_only=True)
         for h, t in fired["num_tokens_since_fired"].items():
             self.num_tokens_since_fired[h].copy_(t)
-        for h, v in (fired.get("best_loss") or {}).items():
-            if h in self.best_loss:
-                self.best_loss[h] = v
+        saved_best = fired.get("best_loss") or {}
+        if isinstance(saved_best, dict) and isinstance(self.best_loss, dict):
+            for h, v in saved_best.items():
+                if h in self.best_loss:
+                    self.best_loss[h] = v
         return self
 
     # The reference gathers the tp shards of every optimizer state tensor to rank 0 and writes ONE flattened
@@ -306,6 +316,8 @@ class TPTrainer(FitLoop):
                 mine = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()
                         if k not in ("exp_avg", "exp_avg_sq")}  # (torch.optim.Adam's per-parameter step)
                 for key in ("exp_avg", "exp_avg_sq"):
+                    if key not in st:  # (an optimizer without moments, or a file saved before the first step)
+                        continue
                     t = st[key]
                     if sharded:
                         t = t[sae.lat_begin:sae.lat_begin + sae.m_local]

@@ -233,9 +233,13 @@ class Trainer(EndToEnd, FitLoop):
         for h, t in rank_state["num_tokens_since_fired"].items():
             if h in self.num_tokens_since_fired:
                 self.num_tokens_since_fired[h].copy_(t)
-        for h, v in rank_state.get("best_loss", {}).items():
-            if h in self.best_loss:
-                self.best_loss[h] = v
+        saved_best = rank_state.get("best_loss", {})
+        if not isinstance(saved_best, dict):  # one scalar for the end-to-end losses (trainer.py:294-295)
+            self.best_loss = saved_best
+        elif isinstance(self.best_loss, dict):
+            for h, v in saved_best.items():
+                if h in self.best_loss:
+                    self.best_loss[h] = v
         for i, sch in enumerate(self.lr_schedulers):
             sch.load_state_dict(torch.load(path / f"lr_scheduler_{i}.pt", weights_only=True))
         for i, opt in enumerate(self.optimizers):

@@ -96,3 +96,62 @@ def test_load_many_local(tmp_path):
     ref = SparseCoder(8, SparseCoderConfig(transcode=True, expansion_factor=2, k=2), "cpu", dtype=torch.float32)
     assert torch.equal(got["h.2.mlp"].encoder.weight, ref.encoder.weight)
     assert list(SparseCoder.load_many(str(tmp_path), local=True, layers=["h.9.mlp", "h.10.mlp"])) == ["h.9.mlp", "h.10.mlp"]
+
+
+def test_empty_optimizer_state_round_trips_through_the_file_layout():
+    """SignSGD keeps no state and Adam has none before its first step: the flattened file then holds no ``state`` leaf
+    and the loader must hand ``Optimizer.load_state_dict`` an empty one."""
+    from clt_training_amd import ckpt
+
+    p = torch.nn.Parameter(torch.zeros(4))
+    for opt in (torch.optim.SGD([p], lr=0.5), torch.optim.Adam([p], lr=0.5)):
+        flat = ckpt.to_reference_layout(opt.state_dict(), 0)
+        assert not any(k[0] == "state" for k in flat)
+        nested, step = ckpt.from_file_layout(flat)
+        assert nested["state"] == {} and step == 0
+        opt.load_state_dict(nested)  # raised KeyError('state') before
+        assert opt.param_groups[0]["lr"] == 0.5
+
+
+def test_fit_logs_the_end_to_end_keys_and_ranks_best_by_the_trained_loss(tmp_path):
+    """trainer.py:829-851, 972-989: ``ce_loss`` / ``kl_loss`` + ``acc_top1`` are logged, ``fvu/...`` only when "fvu" is in
+    the loss name, and save_best compares ONE scalar for the end-to-end losses."""
+    from types import SimpleNamespace
+
+    from clt_training_amd.fit_loop import FitLoop
+
+    class Stub(FitLoop):
+        def __init__(self, loss_fn, losses):
+            self.cfg = SimpleNamespace(loss_fn=loss_fn, grad_acc_steps=1, micro_acc_steps=1, wandb_log_frequency=1,
+                                       save_every=2, save_best=True, log_to_wandb=False, restart_epoch=False,
+                                       save_dir=str(tmp_path), run_name="r", hookpoints=["h"], dead_feature_threshold=10,
+                                       k_decay_steps=0, k_anneal_mul=1, sae=SimpleNamespace(k=4), per_layer_k=[])
+            self.saes = {"h": SimpleNamespace(num_latents=8)}
+            self.num_tokens_since_fired = {"h": torch.zeros(8)}
+            self.dataset, self.losses, self.global_step = list(range(len(losses))), losses, 0
+            self.saved, self.logged = [], []
+            self.init_k_schedule()
+            self.wandb_log = lambda info, step: self.logged.append((step, info))
+
+        def step(self, batch):
+            v = torch.tensor(self.losses[batch])
+            self.last_e2e = {"kl": v, "acc_top1": torch.tensor(0.5)} if "kl" in self.cfg.loss_fn else {"ce": v}
+            self.global_step += 1
+            return {"h": torch.tensor(0.25)}
+
+        def save(self, path=None, only=None):
+            self.saved.append((path, only))
+
+    t = Stub("kl", [3.0, 2.0, 5.0, 4.0]).fit()
+    assert [set(i) for _, i in t.logged] == [{"kl_loss", "acc_top1", "dead_pct/h", "k"}] * 4
+    assert [i["kl_loss"] for _, i in t.logged] == [3.0, 2.0, 5.0, 4.0]
+    best = [p for p, _ in t.saved if p is not None]
+    # (step + 1) % save_every with step already advanced: the reference saves after batches 1 and 3 (3.0, then 5.0)
+    assert best == [f"{tmp_path}/r/best"] and t.best_loss == 3.0
+    t = Stub("kl-fvu", [1.0]).fit()
+    assert set(t.logged[0][1]) == {"kl_loss", "acc_top1", "dead_pct/h", "fvu/h", "k"}
+    t = Stub("ce", [1.0, 0.5]).fit()
+    assert set(t.logged[0][1]) == {"ce_loss", "dead_pct/h", "k"} and t.best_loss == 0.5
+    t = Stub("fvu", [1.0, 0.5]).fit()
+    assert set(t.logged[0][1]) == {"dead_pct/h", "fvu/h", "k"} and t.best_loss == {"h": 0.25}
+    assert (f"{tmp_path}/r/best/h", ["h"]) in t.saved
