@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libcltmi355.so"
-SOURCES = ["common.hip", "decode.hip", "segments.hip", "decode_rows.hip", "topk.hip", "encoder_gemm.hip", "encoder_gemm_fast.hip", "encoder_gemm_fast16.hip", "fvu.hip", "adam.hip"]
+SOURCES = ["common.hip", "decode.hip", "segments.hip", "decode_rows.hip", "topk.hip", "encoder_gemm.hip", "encoder_gemm_fast.hip", "encoder_gemm_fast16.hip", "encoder_gemm_w8.hip", "fvu.hip", "adam.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

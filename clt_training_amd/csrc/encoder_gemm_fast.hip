@@ -603,8 +603,10 @@ static int grid_for(int64_t ntiles, int cus) { return (int)(ntiles < cus ? ntile
 int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_t st) {
   const int grid = grid_for((int64_t)a.nlt * a.ntt, cus);
   if (grid <= 0) return CLT_OK;
-  if (gemm_fast16_ok(a.M, a.kbytes) && !(a.dbg & 64))  // (-DCLT_TUNING builds: CLT_GEMM_DEBUG 64 = the 32x32x16 kernel)
+  if (gemm_fast16_ok(a.M, a.kbytes) && !(a.dbg & 64)) {  // (-DCLT_TUNING builds: CLT_GEMM_DEBUG 64 = the 32x32x16 kernel,
+    if (filter && !(a.dbg & 128)) return launch_gemm_w8_filter(a, grid, st);  // 128 = the four-wave filter pass)
     return launch_gemm_fast16(a, out_dtype, filter, grid, st);
+  }
   if (filter)
     hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, 1>), dim3(grid), dim3(NTHREADS), 0, st, a);
   else if (out_dtype == CLT_BF16)

@@ -1,0 +1,463 @@
+// Filter pass of the fused encode + top-k (gemm_fast.h) on TWO waves per SIMD: the encoder GEMM
+// pre[N, M] = relu(x[N, d] @ W[M, d]^T + b) in bf16 on v_mfma_f32_16x16x32_bf16 whose epilogue keeps only the
+// accumulators that reach their token's threshold.
+//
+// Same workgroup tile, LDS image, LDS-DMA ring, product orientation (D[latent][token]) and candidate-list format as
+// encoder_gemm_fast16.hip, but the 256 x 256 tile is split over EIGHT waves (512 threads, 2 latent halves x 4 token
+// quarters, 128 latents x 64 tokens per wave) instead of four:
+//   * a wave holds 128 accumulators instead of 256, and at 256 registers per lane hipcc keeps them in ARCHITECTURAL
+//     VGPRs (no "a" operand anywhere in this file): the threshold scan reads them in place -- no v_accvgpr_read, a
+//     quarter of the old scan's instructions;
+//   * what one wave per SIMD could not hide under its own MFMAs -- the issue cost of the LDS-DMAs (25-40 cycles
+//     each), the scan, the waits -- now runs beside the partner wave's MFMAs (MI355X_MICROARCH.md, 'Two waves per
+//     SIMD'); per wave and k-step: 32 MFMAs, 12 fragment reads (8 of W, 4 of x), 4 LDS-DMAs;
+//   * the price is 12 instead of 8 ds_read_b128 per 32 MFMAs: 96 KiB of fragment reads per CU and k-step, ~40 % of
+//     what the LDS array delivers at the ideal MFMA rate (256 B/clk for ds_read_b128).
+// The accumulation order per output element is the four-wave kernel's (bias MFMA, then the k-steps in order), so the
+// accumulators -- and with them the fused path's results -- are bit-identical.
+// MFMA-bound: 2 * N * M * d flops per launch.
+#include <math.h>
+
+#include <utility>
+
+#include "gemm_fast_dev.h"
+
+namespace clt {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+constexpr int NT8 = 512;     // threads: 8 waves, wave = (wm = wave >> 2: latent half, wn = wave & 3: token quarter)
+constexpr int PF8 = 4;       // stages the loader runs ahead of the multiplier (= ring slots: see encoder_gemm_fast16.hip)
+constexpr int STAGE8 = 2 * OP_BYTES;
+constexpr int AUX8_OFF = NSTAGE * STAGE8;
+constexpr int AUX8_WAVE = 256;  // a wave's aux piece: [0, 128) bias of latents 32 w .. + 31, [128, 256) tau of tokens 32 w .. + 31
+constexpr int QUEUE8_OFF = AUX8_OFF + 2 * 8 * AUX8_WAVE;
+constexpr int QLANE8 = 7;    // 8-byte hit-queue entries per lane between flushes (3.5 KiB per wave)
+constexpr int NDMA8 = 4;     // data LDS-DMAs per wave and stage: 2 W pieces, 2 x pieces
+static_assert(QUEUE8_OFF + 8 * QLANE8 * 64 * 8 <= 160 * 1024, "LDS");
+
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Instruction slots of a k-step (slot t = after MFMA t): the certification wait + barrier after MFMA 1, the twelve
+// fragment reads of the next step after MFMAs 2, 4, .. 24, the four LDS-DMAs after MFMAs 5, 11, 17, 23 (an operand's m0
+// write goes with its first piece).
+__host__ __device__ constexpr int dma8_at(int t) { return (t >= 5 && (t - 5) % 6 == 0 && (t - 5) / 6 < 4) ? (t - 5) / 6 : -1; }
+__host__ __device__ constexpr int read8_at(int t) { return (t >= 2 && t % 2 == 0 && (t - 2) / 2 < 12) ? (t - 2) / 2 : -1; }
+
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+__device__ __forceinline__ void set_m0(uint32_t v) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(v) : "memory", "m0");
+}
+// LDS[m0 + OFF + 16 * lane] = *(sbase + voff + OFF)
+template <int OFF>
+__device__ __forceinline__ void dma_m0(const char* sbase, uint32_t voff) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+// the aux piece: lanes of `mask` only (every lane of the wave is active here: uniform control flow)
+__device__ __forceinline__ void dma_aux(const char* src, uint32_t lds_dst, unsigned long long mask) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_mov_b64 exec, %2\n\t"
+      "global_load_lds_dwordx4 %0, off\n\t"
+      "s_mov_b64 exec, -1"
+      :
+      : "v"(src), "s"(lds_dst), "s"(mask)
+      : "memory", "m0");
+}
+// All LDS reads of this wave have returned; every fragment passes through the statement, so no MFMA that consumes one
+// can be moved above the wait.
+__device__ __forceinline__ void frag_wait(u32x4 (&A)[8], u32x4 (&B)[4]) {
+  u32x4 a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], a6 = A[6], a7 = A[7];
+  u32x4 b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3];
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+  asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+  A[0] = a0, A[1] = a1, A[2] = a2, A[3] = a3, A[4] = a4, A[5] = a5, A[6] = a6, A[7] = a7;
+  B[0] = b0, B[1] = b1, B[2] = b2, B[3] = b3;
+}
+
+__global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
+  __shared__ __attribute__((aligned(1024))) char lds[QUEUE8_OFF + 8 * QLANE8 * 64 * 8];
+  const int ntt = p.ntt;
+  const char* __restrict__ xb = p.x;
+  const char* __restrict__ Wb = p.W;
+  const char* __restrict__ bias = p.bias;
+  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt, dbg = p.dbg;
+  const int64_t N = p.N, M = p.M;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int c16 = lane & 15, hq = lane >> 4;
+
+  // ---- this workgroup's tile ids (as encoder_gemm_fast.hip): XCD group blockIdx % 8 owns a contiguous id range
+  const int ntiles = nlt * ntt;
+  const int xg = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int nbx = ((int)gridDim.x - xg + 7) >> 3;
+  const int qt = ntiles >> 3, rr = ntiles & 7;
+  const int xstart = xg < rr ? xg * (qt + 1) : rr * (qt + 1) + (xg - rr) * qt;
+  const int xcount = qt + (xg < rr ? 1 : 0);
+  const int my_tiles = bi < xcount ? uni((xcount - bi + nbx - 1) / nbx) : 0;
+  if (my_tiles == 0) return;
+
+  const int nsteps = kbytes / ROWB;  // even and >= PF8 (host: gemm_fast16_ok)
+  const int total = my_tiles * nsteps;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+  const char* zero = reinterpret_cast<const char*>(g_zero16);
+
+  // Tile id -> (virtual latent tile, token tile), carried incrementally (encoder_gemm_fast16.hip).
+  struct TilePos {
+    int pp, rem, pt, full;
+  };
+  auto pos_panel = [&](TilePos& c) {
+    const int left = ntt - c.pp * GEMM_PANEL;
+    c.pt = left < GEMM_PANEL ? left : GEMM_PANEL;
+    c.full = nlt * c.pt;
+  };
+  auto pos_init = [&](TilePos& c, int id) {
+    const int fullp = nlt * GEMM_PANEL;
+    c.pp = uni(id / fullp);
+    c.rem = uni(id - c.pp * fullp);
+    pos_panel(c);
+  };
+  auto pos_next = [&](TilePos& c) {
+    c.rem += nbx;
+    while (c.rem >= c.full) {
+      c.rem -= c.full;
+      ++c.pp;
+      pos_panel(c);
+    }
+  };
+  auto pos_get = [&](const TilePos& c, int& lt, int& tt) {
+    if (c.pt == GEMM_PANEL) {
+      lt = c.rem >> 3;
+      tt = c.pp * GEMM_PANEL + (c.rem & 7);
+    } else {
+      lt = uni(c.rem / c.pt);
+      tt = uni(c.pp * GEMM_PANEL + c.rem % c.pt);
+    }
+  };
+  static_assert(GEMM_PANEL == 8, "pos_get shifts by 3");
+  TilePos ld_pos, cur_pos;
+  pos_init(ld_pos, xstart + bi);
+  cur_pos = ld_pos;
+
+  // ---- loader state: runs PF8 stages ahead of the multiplier, possibly in the next tile.  Past the last stage it keeps
+  //      re-fetching the last tile into ring slots nobody reads again, so that every k-step issues the same NDMA8
+  //      operations and the counted waits need no special cases.
+  int ld_t = 0, ld_ks = 0, ld_slot = 0;
+  const char* ldW = Wb;
+  const char* ldX = xb;
+  const char* ldA = zero;  // per-lane source of the aux piece: bias chunk (lanes < nl <= 8) or tau chunk (lanes 8 .. 15)
+  uint32_t voffW[2], voffX[2];
+  const int nl = 32 * bias_esize / 16;  // lanes of the bias piece (this wave's 32 latents)
+  const unsigned long long aux_mask = __ballot(lane < nl || (lane >= 8 && lane < 16));
+  const int ntt_layer = p.ntt_layer;
+  const int ldx = ntt_layer ? (int)p.ldx_bytes : kbytes;  // bytes between consecutive token rows of x
+  const char* __restrict__ xp = p.xp;                      // packed copy of x (fused path), or null
+  const int64_t xstep = xp ? p.xp_kstep_bytes : ROWB;      // bytes from one k-step of x to the next
+  constexpr int DMA_BIAS = 1024;  // piece q is loaded with immediate q * 1024: lane offsets carry + 1024 - q * 1024 >= 0
+  auto loader_tile = [&](int lt, int tt) {
+    const int64_t lat0 = (int64_t)lt_actual(lt, p.lt_mode, p.lt_S) * GEMM_TM, tok0 = (int64_t)tt * GEMM_TN;
+    const char* Wt = Wb;
+    const char* bt = bias;
+    if (ntt_layer) {  // stacked layers: this token tile's layer picks the table, the bias and the x block
+      const int layer = uni(tt / ntt_layer);
+      Wt = p.Wl[layer];
+      bt = p.biasl[layer];
+      ldX = xb + (int64_t)layer * p.x_layer_bytes + (int64_t)(tt - layer * ntt_layer) * GEMM_TN * ldx - DMA_BIAS;
+    } else {
+      ldX = xb + tok0 * kbytes - DMA_BIAS;
+    }
+    if (xp) ldX = xp + tok0 * ROWB - DMA_BIAS;  // packed copy [k-step][token][64 B]: a piece is 1 KiB of consecutive bytes
+    ldW = Wt + lat0 * kbytes - DMA_BIAS;
+    // rows past the end re-read the last row (their products are never stored)
+    const int maxW = (int)(M - 1 - lat0 < GEMM_TM ? M - 1 - lat0 : GEMM_TM);
+    const int maxX = (int)(N - 1 - tok0 < GEMM_TN ? N - 1 - tok0 : GEMM_TN);  // (stacked layers: N_l % 256 == 0)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = (wave * 2 + q) * 16 + (lane >> 2);  // wave w stages rows 32 w .. 32 w + 31 of either operand
+      const int c = (lane & 3) ^ ((0 - (r >> 2)) & 3);  // the bank swizzle of encoder_gemm_fast16.hip
+      voffW[q] = (uint32_t)((r < maxW ? r : maxW) * kbytes + c * 16 + DMA_BIAS - q * 1024);
+      voffX[q] = xp ? (uint32_t)(r * ROWB + c * 16 + DMA_BIAS - q * 1024)  // (padding rows exist in the packed copy)
+                    : (uint32_t)((r < maxX ? r : maxX) * ldx + c * 16 + DMA_BIAS - q * 1024);
+    }
+    const int epc = 16 / bias_esize;
+    const int64_t lat = lat0 + 32 * wave + lane * epc;
+    ldA = (bt && lane < nl && lat + epc <= M) ? bt + lat * bias_esize : zero;
+    if (lane >= 8 && lane < 16)  // tau is padded to a multiple of 256 tokens
+      ldA = reinterpret_cast<const char*>(p.tau + tok0 + wave * 32 + (lane - 8) * 4);
+  };
+  // LDS-DMA operation u of a stage: 0 = m0 for W, 1..2 W pieces, 3 = m0 for x, 4..5 x pieces, 6 aux piece (tile parity
+  // ld_t & 1: the aux pieces of the running tile stay put while the loader is in the next one)
+  auto dma = [&](auto uc, uint32_t stage_lds, int kb0) {
+    constexpr int u = decltype(uc)::value;
+    if constexpr (u == 0) set_m0(stage_lds + wave * 2048);
+    else if constexpr (u <= 2) dma_m0<(u - 1) * 1024>(ldW + kb0, voffW[u - 1]);
+    else if constexpr (u == 3) set_m0(stage_lds + OP_BYTES + wave * 2048);
+    else if constexpr (u <= 5) dma_m0<(u - 4) * 1024>(ldX + (int64_t)(kb0 / ROWB) * xstep, voffX[u - 4]);
+    else if (kb0 == 0)  // a tile's first stage (wave-uniform): the tile's aux piece; lane l lands at + 16 l
+      dma_aux(ldA, lds0 + AUX8_OFF + ((ld_t & 1) * 8 + wave) * AUX8_WAVE, aux_mask);
+  };
+  auto loader_advance = [&]() {
+    ld_slot = (ld_slot + 1) & 3;
+    if (++ld_ks == nsteps) {
+      ld_ks = 0;
+      if (++ld_t < my_tiles) {
+        int lt, tt;
+        pos_next(ld_pos);
+        pos_get(ld_pos, lt, tt);
+        loader_tile(lt, tt);
+      }
+    }
+  };
+
+  // ---- fragment addresses (encoder_gemm_fast16.hip): row * 64 + (chunk ^ swizzle) * 16, chunk = hq
+  const int swz = (0 - (c16 >> 2)) & 3;
+  const uint32_t fa = (uint32_t)((wm * 128 + c16) * ROWB + ((hq ^ swz) * 16));
+  const uint32_t fb = (uint32_t)(OP_BYTES + (wn * 64 + c16) * ROWB + ((hq ^ swz) * 16));
+  // piece pc of a stage's fragment set, in the order the MFMAs need them: A0 B0 .. B3 A1 .. A7
+  auto read_piece = [&](auto pcc, uint32_t sa, uint32_t sb, u32x4 (&A)[8], u32x4 (&B)[4]) {
+    constexpr int pc = decltype(pcc)::value;
+    if constexpr (pc == 0) A[0] = lds_read128<0>(sa);
+    else if constexpr (pc <= 4) B[pc - 1] = lds_read128<(pc - 1) * 16 * ROWB>(sb);
+    else A[pc - 4] = lds_read128<(pc - 4) * 16 * ROWB>(sa);
+  };
+
+  f32x4 acc[8][4];
+  u32x4 FA0[8], FB0[4], FA1[8], FB1[4];
+
+  // The bias enters as three extra K columns (encoder_gemm_fast.hip): A = (b_hi, b_mid, b_lo, 0...) of this lane's
+  // latent, B = (1, 1, 1, 0...), both in the lanes of K chunk 0.
+  auto init_acc = [&](int par) {
+    const char* st = lds + AUX8_OFF + par * 8 * AUX8_WAVE;
+    const u32x4 zero_f = {0u, 0u, 0u, 0u}, ones_f = {0x3f803f80u, 0x00003f80u, 0u, 0u};
+    const u32x4 ones = hq == 0 ? ones_f : zero_f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int off = wm * 128 + i * 16 + c16;  // latent in the tile: aux piece of wave off / 32
+      const char* bp = st + (off >> 5) * AUX8_WAVE + (off & 31) * bias_esize;
+      float b;
+      if (bias_esize == 4) b = *reinterpret_cast<const float*>(bp);
+      else b = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(bp));
+      const uint32_t u0 = __float_as_uint(b) & 0xffff0000u;  // truncation splits: every remainder is exact
+      const float r1 = b - __uint_as_float(u0);
+      const uint32_t u1 = __float_as_uint(r1) & 0xffff0000u;
+      const float r2 = r1 - __uint_as_float(u1);
+      const uint32_t u2 = __float_as_uint(r2) & 0xffff0000u;
+      const u32x4 bias_f = {(u0 >> 16) | u1, u2 >> 16, 0u, 0u};
+      const u32x4 Ab = hq == 0 ? bias_f : zero_f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x4 oj = ones;
+        asm volatile("" : "+v"(oj));  // independent MFMAs, not one plus accumulator moves
+        acc[i][j] = mfma16(Ab, oj, zero4);
+      }
+    }
+  };
+
+  // ---- prologue: PF8 stages in flight, all landed before the first MFMA (once per launch)
+  int cur_lt, cur_tt;
+  pos_get(cur_pos, cur_lt, cur_tt);
+  loader_tile(cur_lt, cur_tt);
+#pragma unroll 1
+  for (int pp = 0; pp < PF8; ++pp) {
+    const uint32_t st = lds0 + (uint32_t)ld_slot * STAGE8;
+    static_for<7>([&](auto uc) { dma(uc, st, ld_ks * ROWB); });
+    loader_advance();
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  static_for<12>([&](auto pcc) { read_piece(pcc, lds0 + fa, lds0 + fb, FA0, FB0); });
+  init_acc(0);
+
+  // One k-step: 32 MFMAs out of (Ac, Bc); in their shadows the certification of stage s + 1, the NDMA8 LDS-DMAs of
+  // stage s + PF8 (into the slot of stage s, whose fragments are in registers) and the 12 fragment reads of stage s + 1
+  // into (An, Bn).  Stage s + 1 has landed once only the operations issued after its LDS-DMAs are outstanding: the
+  // 2 NDMA8 data DMAs of stages s + 2 and s + 3 (an aux piece or the list stores of an epilogue among the older
+  // operations only make the wait stricter).  The barrier also tells every wave that all eight have finished reading
+  // stage s (frag_wait: this wave's reads, issued during the step before, have returned).
+  auto kstep = [&](u32x4 (&Ac)[8], u32x4 (&Bc)[4], u32x4 (&An)[8], u32x4 (&Bn)[4], uint32_t nb, uint32_t ld_stage,
+                   int kb0) {
+    frag_wait(Ac, Bc);
+    const uint32_t sa = nb + fa, sb = nb + fb;
+    CLT_FENCE();
+    static_for<32>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int i = t >> 2, j = t & 3;
+      acc[i][j] = mfma16(Ac[i], Bc[j], acc[i][j]);
+      CLT_FENCE();
+      if constexpr (t == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      constexpr int q = dma8_at(t), pc = read8_at(t);
+      if constexpr (q >= 0) {  // (the m0 write of an operand goes with its first piece)
+        if constexpr (q == 0) dma(std::integral_constant<int, 0>{}, ld_stage, kb0);
+        if constexpr (q == 2) dma(std::integral_constant<int, 3>{}, ld_stage, kb0);
+        dma(std::integral_constant<int, (q < 2 ? q + 1 : q + 2)>{}, ld_stage, kb0);
+        if constexpr (q == 3) dma(std::integral_constant<int, 6>{}, ld_stage, kb0);
+      }
+      if constexpr (pc >= 0) read_piece(std::integral_constant<int, pc>{}, sa, sb, An, Bn);
+      CLT_FENCE();
+    });
+  };
+  static_assert(2 * NDMA8 == 8, "the counted wait of kstep");
+
+  int ks = 0, t_idx = 0;
+#pragma unroll 1
+  for (int s = 0; s < total; s += 2) {
+    const bool last_k = ks + 2 == nsteps;
+    // ---- even step of the pair (never a tile's last: nsteps is even)
+    kstep(FA0, FB0, FA1, FB1, lds0 + (uint32_t)((s + 1) & 3) * STAGE8, lds0 + (uint32_t)ld_slot * STAGE8, ld_ks * ROWB);
+    loader_advance();
+    // ---- odd step
+    kstep(FA1, FB1, FA0, FB0, lds0 + (uint32_t)((s + 2) & 3) * STAGE8, lds0 + (uint32_t)ld_slot * STAGE8, ld_ks * ROWB);
+    loader_advance();
+
+    if (last_k) {
+      const int lt_act = lt_actual(cur_lt, p.lt_mode, p.lt_S);
+      const int64_t lat0 = (int64_t)lt_act * GEMM_TM, tok0 = (int64_t)cur_tt * GEMM_TN;
+      // M is a multiple of 16 (host), so a 16-latent MFMA tile is inside or outside M as a whole: wave-uniform tests
+      const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);
+      // ---- filter epilogue (the scheme of encoder_gemm_fast16.hip): an accumulator that reaches its token's threshold is
+      //      appended, as (bf16 bits << 16 | position in the list's 32 latents), to the private list of this (token,
+      //      latent tile, latent half, lane quarter); the list's length goes to counts.  Scan: per accumulator register
+      //      group (4 latents of one token) an integer max-of-4 read straight from the accumulator VGPRs + ONE compare;
+      //      the four token groups of a latent row are compared together and their masks pinned in SGPR pairs before the
+      //      four wave-uniform branches.  A group with a hit runs a short inline straight-line body: every lane writes
+      //      the group's four values, rounded to bf16, as ONE 8-byte entry at its lane-private LDS queue cursor; only
+      //      lanes with a hit advance the cursor and set the group's bit (i * 4 + j) in a per-lane mask.  A rolled loop
+      //      turns queue entries into list entries, testing each of the four values against the threshold's bf16 value.
+      const int list = (cur_lt * 2 + wm) * 4 + hq;
+      float tl[4];
+      const char* aux = lds + AUX8_OFF + (t_idx & 1) * 8 * AUX8_WAVE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tt = wn * 64 + j * 16 + c16;
+        const float tj = *reinterpret_cast<const float*>(aux + (tt >> 5) * AUX8_WAVE + 128 + (tt & 31) * 4);
+        tl[j] = tok0 + tt < N ? tj : __builtin_inff();
+      }
+      // first entry of the (token j = 0, list) list, in entries; token j adds j * lstride (host: fused_plan checks
+      // that every entry index fits 32 bits)
+      const uint32_t lbase0 = (uint32_t)(((tok0 + wn * 64 + c16) * p.nL + list) * FUSED_SLOTS);
+      const uint32_t lstride = 16u * (uint32_t)p.nL * FUSED_SLOTS;
+      uint2* q = reinterpret_cast<uint2*>(lds + QUEUE8_OFF) + wave * (QLANE8 * 64);
+      // byte cursor into this lane's queue: entry e of lane l sits at q[e * 64 + l]; a full queue keeps overwriting
+      // its last slot while the cursor runs on and reports the overflow
+      char* const qb = reinterpret_cast<char*>(q) + lane * 8;
+      constexpr uint32_t QLAST = (QLANE8 - 1) * 512;
+      uint32_t cntp = 0u;  // the four list lengths of this lane, one byte each
+      bool q_over = false;
+      uint32_t qoff = 0;   // bytes: 512 per entry
+      uint32_t gm = 0u;    // bit i * 4 + j: this lane had a hit in that group
+      const bool qflush = p.qflush != 0;  // wave-uniform (host: fused_plan)
+      if (!(dbg & 2))
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i * 16 < lat_left) {
+          unsigned long long hm[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            // thresholds are positive, so a >= t  <=>  bits(a) >= bits(t) as SIGNED integers
+            const int mx = max(max(__float_as_int(acc[i][jj][0]), __float_as_int(acc[i][jj][1])),
+                               max(__float_as_int(acc[i][jj][2]), __float_as_int(acc[i][jj][3])));
+            hm[jj] = __ballot(mx >= __float_as_int(tl[jj]));
+          }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) asm volatile("" : "+s"(hm[jj]));  // all four masks exist before the first branch
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            if (hm[jj] != 0ull) {
+              uint32_t flag;  // 1 in the lanes with a hit (the mask is already an SGPR pair: one v_cndmask)
+              asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(flag) : "s"(hm[jj]));
+              const bf16x2_t p01 = {(__bf16)acc[i][jj][0], (__bf16)acc[i][jj][1]},
+                             p23 = {(__bf16)acc[i][jj][2], (__bf16)acc[i][jj][3]};
+              *reinterpret_cast<uint2*>(qb + (qoff < QLAST ? qoff : QLAST)) =
+                  make_uint2(__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23));
+              qoff += flag << 9;
+              gm |= flag << (i * 4 + jj);
+            }
+          }
+          CLT_FENCE();
+        }
+        // the queue is turned into list entries after the last latent row or -- when the host expects more than the
+        // queue's QLANE8 - 1 hit groups per lane and tile to be likely (latent shards) -- after every second one
+        if (!(i == 7 || (qflush && (i & 1)))) continue;
+        // ---- queue -> lists (rolled)
+        int nq = (int)(qoff >> 9);
+        q_over = q_over || nq > QLANE8 - 1;  // (slot QLANE8 - 1 is where writes go once the queue is full: not an entry)
+        nq = nq > QLANE8 - 1 ? QLANE8 - 1 : nq;
+#pragma unroll 1
+        for (int e = 0; __ballot(e < nq) != 0ull; ++e) {
+          if (e < nq) {
+            const uint2 ent = q[e * 64 + lane];
+            const int gi = __builtin_ctz(gm);  // the e-th set bit
+            gm &= gm - 1u;
+            const uint32_t j = (uint32_t)gi & 3u, sh = j * 8u, pos0 = ((uint32_t)gi >> 2) * 4u;
+            float tj = tl[0];
+#pragma unroll
+            for (int jj = 1; jj < 4; ++jj) tj = j == (uint32_t)jj ? tl[jj] : tj;
+            // (threshold's bf16 value << 16), at least the smallest positive bf16: zeros carry nothing
+            const uint32_t vm = (__float_as_uint(tj) + 0x8000u) >> 16;
+            const int thr = (int)((vm < 1u ? 1u : vm) << 16);
+            const uint32_t lb = lbase0 + j * lstride;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const uint32_t w = qq < 2 ? ent.x : ent.y;
+              const uint32_t vb = (qq & 1) ? (w & 0xffff0000u) : (w << 16);  // bf16 bits << 16
+              if ((int)vb >= thr) {
+                const uint32_t c = (cntp >> sh) & 255u;
+                if (c < (uint32_t)FUSED_SLOTS && !(dbg & 1)) p.lists[lb + c] = vb | (pos0 + (uint32_t)qq);
+                cntp += 1u << sh;
+              }
+            }
+          }
+        }
+        qoff = 0;
+        gm = 0u;
+        CLT_FENCE();
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t tok = tok0 + wn * 64 + j * 16 + c16;
+        const uint32_t c = (cntp >> (8 * j)) & 255u;  // > FUSED_SLOTS: the merge kernel reports the overflow
+        if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(q_over ? 255u : c);
+      }
+      ks = 0;
+      if (++t_idx < my_tiles) {
+        pos_next(cur_pos);
+        pos_get(cur_pos, cur_lt, cur_tt);
+        init_acc(t_idx & 1);  // its aux pieces came with stage s + 2, certified during the odd step
+      }
+    } else {
+      ks += 2;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing fetches
+}
+
+}  // namespace
+
+// Filter mode only; same shapes as the 16x16x32 four-wave kernel (gemm_fast16_ok).
+int launch_gemm_w8_filter(const FastArgs& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL(gemm_w8_filter_kernel, dim3(grid), dim3(NT8), 0, st, a);
+  CLT_CHECK_LAUNCH("clt_encode_topk_fwd");
+  return CLT_OK;
+}
+
+}  // namespace clt

@@ -75,6 +75,8 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 // least 128, and M a multiple of 16; launch_gemm_fast picks it by this predicate, so the launches of one call agree.
 bool gemm_fast16_ok(int64_t M, int kbytes);
 int launch_gemm_fast16(const FastArgs& a, int out_dtype, bool filter, int grid, hipStream_t st);
+// The filter pass on eight waves, two per SIMD (encoder_gemm_w8.hip): same shapes, same lists, bit-identical accumulators.
+int launch_gemm_w8_filter(const FastArgs& a, int grid, hipStream_t st);
 // xp[a.kbytes / 64][a.ntt * 256][64 B] <- a.x (a.N, a.kbytes, a.ntt and the stacked-layer fields must be set)
 // and zero_ints[0, n_zero) <- 0 (n_zero <= the launch's thread count)
 void launch_pack_x(const FastArgs& a, void* xp, int* zero_ints, int n_zero, hipStream_t st);
