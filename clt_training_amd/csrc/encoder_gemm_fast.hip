@@ -442,9 +442,9 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
                                                            int64_t M, int k, int m, bf16_t* __restrict__ out_vals,
                                                            int64_t* __restrict__ out_idx, int* __restrict__ flag, int l16) {
   constexpr int C = (R - S) * 64;
-  constexpr int NE_CAP = 512;  // non-empty list groups of a token held in LDS between two drains (2 KiB per wave)
+  constexpr int NE_CAP = 512;  // non-empty list groups of a token held in LDS between two drains (4 KiB per wave)
   __shared__ u64 lds_q[4][C];
-  __shared__ uint32_t lds_ne[4][NE_CAP];
+  __shared__ uint32_t lds_ne[4][2 * NE_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
   if (tok >= N) return;
@@ -468,49 +468,50 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
   const uint8_t* crow = counts + tok * nL;
   const uint32_t* lrow = lists + tok * (int64_t)nL * FUSED_SLOTS;
   if (l16) {
-    // lists of the 16x16x32 kernel: l = ((virtual tile * 2 + wm) * 4 + lane quarter), 32 latents each, position
-    // pos = i * 4 + q; the four lists of one (tile, wm) = group g4 have their lengths in one aligned 32-bit word.
-    // Phase 1: the wave reads ALL its length words at once (16-byte loads issued back to back: one memory round trip
-    // instead of one per 64 lists) and compacts the non-empty groups, as (g4 << 16 | four 4-bit lengths), into LDS --
-    // about 150 of 720 at C2.  Phase 2: a lane takes one non-empty group per round and walks its entries; the first
-    // two entries' loads are issued before the first offer.  ~4 dependent round trips per token instead of ~24.
+    // lists of the eight-wave kernel (encoder_gemm_w8.hip): l = ((virtual tile * 2 + wm) * 4 + lane quarter u), 32 latents
+    // each, ONE 8-byte slot per latent row i (four bf16 values: latents 16 i + 4 u + 0 .. 3 of the half tile); counts[l]
+    // is the bit mask of the filled rows, and the four lists of one (tile, wm) = group g4 have their masks in one aligned
+    // 32-bit word (bit 8 u + i).  No list can overflow.
+    // Phase 1: the wave reads ALL its mask words at once (16-byte loads issued back to back: one memory round trip
+    // instead of one per 64 lists) and compacts the non-empty groups, as (g4, mask word), into LDS -- about 150 of 720
+    // at C2.  Phase 2: a lane takes one non-empty group per round and walks its filled slots, the next slot's load
+    // issued before the current one is offered.
     const int nL4 = nL >> 2;
     const uint4* crow16 = reinterpret_cast<const uint4*>(crow);  // nL % 8 == 0 and nL * tok: rows are 8-byte aligned ...
     const uint32_t* crow4 = reinterpret_cast<const uint32_t*>(crow);
-    volatile uint32_t* ne = lds_ne[wave];
+    const uint2* srow = reinterpret_cast<const uint2*>(lists) + tok * (int64_t)nL * 8;
+    volatile uint32_t* ne = lds_ne[wave];  // [NE_CAP] group ids, then [NE_CAP] mask words
     int n_ne = 0;
-    // phase 2 over the groups collected so far (called when the buffer could not take another round of 256 groups --
-    // a token with more than NE_CAP - 256 non-empty groups, e.g. k = 192 with ~500 candidates -- and at the end)
+    // phase 2 over the groups collected so far (called when the buffer could not take another round of 256 groups,
+    // and at the end)
     auto drain = [&]() {
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       for (int r0 = 0; r0 < n_ne; r0 += 64) {
-        const uint32_t ent_ne = r0 + lane < n_ne ? ne[r0 + lane] : 0u;
-        const int g4 = (int)(ent_ne >> 16);
-        const int c0 = ent_ne & 15, c1 = (ent_ne >> 4) & 15, c2 = (ent_ne >> 8) & 15, c3 = (ent_ne >> 12) & 15;
-        const int e1 = c0, e2 = e1 + c1, e3 = e2 + c2, tot = e3 + c3;
+        const bool have = r0 + lane < n_ne;
+        const int g4 = have ? (int)ne[r0 + lane] : 0;
+        uint32_t mask = have ? ne[NE_CAP + r0 + lane] : 0u;
         const unsigned lat_base = (unsigned)lt_actual(g4 >> 1, LT_REST, lt_S) * 256u + (g4 & 1) * 128;
-        auto entry_addr = [&](int e) {
-          const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
-          const int ei = e - (u == 0 ? 0 : u == 1 ? e1 : u == 2 ? e2 : e3);
-          return ((int64_t)g4 * 4 + u) * FUSED_SLOTS + ei;
-        };
-        auto offer_entry = [&](int e, uint32_t ent) {
-          float v = -1.f;
-          unsigned col = 0;
-          if (e < tot) {
-            const int u = e < e1 ? 0 : e < e2 ? 1 : e < e3 ? 2 : 3;
-            v = __uint_as_float(ent & 0xffff0000u);
-            const unsigned pos = ent & 31u;
-            col = lat_base + 4 * u + (pos >> 2) * 16 + (pos & 3);
+        const uint2* grow = srow + (int64_t)g4 * 32;  // 4 lists x 8 slots
+        auto slot_of = [&](uint32_t mk) { return mk ? __builtin_ctz(mk) : 0; };
+        int b = slot_of(mask);
+        uint2 ent = mask ? grow[b] : make_uint2(0u, 0u);
+        while (__ballot(mask != 0u) != 0ull) {
+          const bool cur = mask != 0u;
+          const int bc = b;
+          const uint2 ec = ent;
+          mask &= mask - 1u;
+          b = slot_of(mask);
+          if (mask) ent = grow[b];  // (in flight while the four values below are offered)
+          // slot bc = 8 u + i: latents lat_base + 16 i + 4 u + qq
+          const unsigned col0 = lat_base + (unsigned)(bc & 7) * 16u + (unsigned)(bc >> 3) * 4u;
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const uint32_t w = qq < 2 ? ec.x : ec.y;
+            const float v = __uint_as_float((qq & 1) ? (w & 0xffff0000u) : (w << 16));
+            ws.offer(cur && v >= ws.thr_val && v > 0.f, v, col0 + qq);
           }
-          ws.offer(v >= ws.thr_val && v > 0.f, v, col);
-        };
-        const uint32_t ent0 = 0 < tot ? lrow[entry_addr(0)] : 0u;
-        const uint32_t ent1 = 1 < tot ? lrow[entry_addr(1)] : 0u;
-        offer_entry(0, ent0);
-        if (__ballot(1 < tot) != 0ull) offer_entry(1, ent1);
-        for (int e = 2; __ballot(e < tot) != 0ull; ++e) offer_entry(e, e < tot ? lrow[entry_addr(e)] : 0u);
+        }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);  // (the LDS reads above are done before the next round overwrites the buffer)
       __builtin_amdgcn_wave_barrier();
@@ -530,17 +531,10 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        uint32_t pk = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          uint32_t c = (cw[u] >> (8 * b)) & 255u;
-          if (c > (uint32_t)FUSED_SLOTS) over = true, c = FUSED_SLOTS;
-          pk |= c << (4 * b);
-        }
-        const bool nz = pk != 0u;
+        const bool nz = cw[u] != 0u;
         const unsigned long long bm = __ballot(nz);
         const int pos = n_ne + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
-        if (nz) ne[pos] = ((uint32_t)(wb + u) << 16) | pk;  // pos < n_ne + 256 <= NE_CAP
+        if (nz) ne[pos] = (uint32_t)(wb + u), ne[NE_CAP + pos] = cw[u];  // pos < n_ne + 256 <= NE_CAP
         n_ne += __popcll(bm);
       }
     }
@@ -603,9 +597,9 @@ static int grid_for(int64_t ntiles, int cus) { return (int)(ntiles < cus ? ntile
 int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_t st) {
   const int grid = grid_for((int64_t)a.nlt * a.ntt, cus);
   if (grid <= 0) return CLT_OK;
-  if (gemm_fast16_ok(a.M, a.kbytes) && !(a.dbg & 64)) {  // (-DCLT_TUNING builds: CLT_GEMM_DEBUG 64 = the 32x32x16 kernel,
-    if (filter && !(a.dbg & 128)) return launch_gemm_w8_filter(a, grid, st);  // 128 = the four-wave filter pass)
-    return launch_gemm_fast16(a, out_dtype, filter, grid, st);
+  if (gemm_fast16_ok(a.M, a.kbytes) && !(a.dbg & 64)) {  // (-DCLT_TUNING builds: CLT_GEMM_DEBUG 64 = the 32x32x16 kernels)
+    if (filter) return launch_gemm_w8_filter(a, grid, st);  // eight waves, slot-per-row candidate lists
+    return launch_gemm_fast16(a, out_dtype, grid, st);
   }
   if (filter)
     hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, 1>), dim3(grid), dim3(NTHREADS), 0, st, a);
@@ -669,18 +663,28 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   pl.ntt = (int)ntt;
   pl.l16 = gemm_fast16_ok(M, d * 2) && !(tuning_env("CLT_GEMM_DEBUG", 0) & 64);
   pl.nL = (int)nltB * (pl.l16 ? 8 : 4);
-  // the filter kernels address list entries with 32 bits
-  if ((int64_t)ntt * GEMM_TN * pl.nL * FUSED_SLOTS >= (1ll << 32)) return pl;
+  // the filter kernels address list entries with 32 bits: over all tokens (32x32x16 kernel: entry index) or inside a
+  // token tile (eight-wave kernel: byte offset from the tile's first list)
+  if (!pl.l16 && (int64_t)ntt * GEMM_TN * pl.nL * FUSED_SLOTS >= (1ll << 32)) return pl;
+  if (pl.l16 && ((int64_t)GEMM_TN * pl.nL << 6) >= (1ll << 32)) return pl;
   pl.lds = nltA * GEMM_TM;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
-  pl.off_pre_s = take((size_t)N * pl.lds * 2);
+  if (pl.l16) {
+    // eight-wave kernel: 8 slots of 8 bytes per list, written sparsely -- 2 bytes per non-sample latent, the size of the
+    // bf16 pre-activation matrix they replace.  The sample matrix is dead once its row top-k has run, before the filter
+    // pass writes the first slot (stream order): the lists lie over it.
+    const size_t lists_bytes = (size_t)N * pl.nL * 64, sample_bytes = (size_t)N * pl.lds * 2;
+    pl.off_pre_s = pl.off_lists = take(lists_bytes > sample_bytes ? lists_bytes : sample_bytes);
+  } else {
+    pl.off_pre_s = take((size_t)N * pl.lds * 2);
+    pl.off_lists = take((size_t)N * pl.nL * FUSED_SLOTS * 4);  // FUSED_SLOTS u32 entries per list
+  }
   pl.off_svals = take((size_t)N * k * 2);
   pl.off_sidx = take((size_t)N * k * 8);
   pl.off_tau = take((size_t)ntt * GEMM_TN * 4);
   pl.off_counts = take((size_t)N * pl.nL);
-  pl.off_lists = take((size_t)N * pl.nL * FUSED_SLOTS * 4);
-  pl.off_xp = take(pl.l16 ? (size_t)ntt * GEMM_TN * d * 2 : 0);  // packed x (16x16x32 kernel)
+  pl.off_xp = take(pl.l16 ? (size_t)ntt * GEMM_TN * d * 2 : 0);  // packed x (16x16x32 kernels)
   pl.bytes = off;
   pl.ok = true;
   return pl;

@@ -39,10 +39,9 @@ constexpr int PF = 4;       // stages the loader runs ahead of the multiplier
 constexpr int STAGE16 = 2 * OP_BYTES;
 constexpr int AUX16_OFF = NSTAGE * STAGE16;
 constexpr int QUEUE16_OFF = AUX16_OFF + 2 * 4 * AUX_WAVE;
-constexpr int QLANE16 = 13;  // filter mode: 8-byte hit-queue entries per LANE between flushes (6.5 KiB per wave)
 constexpr int STG_WAVE = 16 * 256;  // store mode, bf16: a wave's staging area for one 16-token x 128-latent block
 constexpr int NDMA16 = 8;    // data LDS-DMAs per wave and stage (a tile's first stage has the aux piece on top)
-static_assert(QUEUE16_OFF + 4 * QLANE16 * 64 * 8 <= 160 * 1024, "LDS");
+static_assert(QUEUE16_OFF + 4 * STG_WAVE <= 160 * 1024, "LDS");
 static_assert(2 * NDMA16 == 16 && 2 * NDMA16 + NSTORE >= 63 && NSTORE == 64, "the counted waits of kstep assume these");
 
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -128,10 +127,11 @@ __device__ __forceinline__ void frag_wait(u32x4 (&A)[8], u32x4 (&B)[8]) {
   B[0] = b0, B[1] = b1, B[2] = b2, B[3] = b3, B[4] = b4, B[5] = b5, B[6] = b6, B[7] = b7;
 }
 
-// MODE 0: store relu(pre) (OT = bf16 or f32).  MODE 1: per-token threshold filter, no pre matrix (see FastArgs).
-template <typename OT, int MODE>
+// Store mode: relu(pre) as OT = bf16 or f32 (pass A of the fused encode + top-k, its fallback, clt_encoder_gemm_relu).
+// The filter pass of the fused path runs on eight waves: encoder_gemm_w8.hip.
+template <typename OT>
 __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[QUEUE16_OFF + (MODE == 1 ? 4 * QLANE16 * 64 * 8 : sizeof(OT) == 2 ? 4 * STG_WAVE : 0)];
+  __shared__ __attribute__((aligned(1024))) char lds[QUEUE16_OFF + (sizeof(OT) == 2 ? 4 * STG_WAVE : 0)];
   int ntt = p.ntt;
   if (p.gate) {  // fallback launch: runs only if the fused path raised a flag
     const int flagged = *p.gate;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
   const char* ldA = zero;  // per-lane source of the aux piece: bias chunk (lanes < nl <= 16) or tau chunk (lanes 16 .. 47)
   uint32_t voffW[4], voffX[4];
   const int nl = 64 * bias_esize / 16;  // lanes of the bias piece (this wave's 64 latents)
-  const unsigned long long aux_mask = __ballot(lane < nl || (MODE == 1 && lane >= 16 && lane < 48));
+  const unsigned long long aux_mask = __ballot(lane < nl);
   const int ntt_layer = p.ntt_layer;
   const int ldx = ntt_layer ? (int)p.ldx_bytes : kbytes;  // bytes between consecutive token rows of x
   const char* __restrict__ xp = p.xp;                      // packed copy of x (fused path), or null
@@ -248,8 +248,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
     const int epc = 16 / bias_esize;
     const int64_t lat = lat0 + 64 * wave + lane * epc;
     ldA = (bt && lat + epc <= M) ? bt + lat * bias_esize : zero;
-    if (MODE == 1 && lane >= 16 && lane < 48)  // tau is padded to a multiple of 256 tokens
-      ldA = reinterpret_cast<const char*>(p.tau + tok0 + wn * 128 + (lane - 16) * 4);
   };
   // LDS-DMA operation u of a stage: 0 = m0 for W, 1..4 W pieces, 5 = m0 for x, 6..9 x pieces, 10 aux piece (tile parity
   // ld_t & 1: the aux pieces of the running tile stay put while the loader is in the next one)
@@ -409,7 +407,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
       const int64_t lat0 = (int64_t)lt_act * GEMM_TM, tok0 = (int64_t)cur_tt * GEMM_TN;
       // M is a multiple of 16 (host), so a 16-latent MFMA tile is inside or outside M as a whole: wave-uniform tests
       const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);
-      if constexpr (MODE == 0) {
+      {
         // ---- store epilogue: ReLU, one rounding.  bf16: each 16-token x 128-latent block goes through a wave-private
         //      staging area in LDS (row = token, 256 B; 16-byte chunk c of row r at position c ^ r: the 8-byte writes of
         //      a lane = (token, 4 latents) spread over all banks and the 16-byte reads of a lane = (token, 8 latents) are
@@ -467,123 +465,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
           }
           if (interior) stores_behind = 3;
         }
-      } else {
-        // ---- filter epilogue (the scheme of encoder_gemm_fast.hip in this accumulator layout): an accumulator that
-        //      reaches its token's threshold is appended, as (bf16 bits << 16 | position in the list's 32 latents), to
-        //      the private list of this (token, latent tile, latent half, lane quarter); the list's length goes to
-        //      counts.  Scan: per accumulator register group (4 latents of one token) 4 reads + integer max-of-4 + ONE
-        //      compare; four token groups are compared together and their masks pinned in SGPR pairs before the four
-        //      wave-uniform branches.  A group with a hit runs a short inline straight-line body: every lane writes the
-        //      group's four values, rounded to bf16, as ONE 8-byte entry at its lane-private LDS queue cursor; only
-        //      lanes with a hit advance the cursor and set the group's bit (i * 8 + j) in a per-lane mask.  A rolled
-        //      loop turns queue entries into list entries, testing each of the four values against the threshold's
-        //      bf16 value.
-        const int list = (cur_lt * 2 + wm) * 4 + hq;
-        float tl[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int64_t tok = tok0 + wn * 128 + j * 16 + c16;
-          const float tj = *reinterpret_cast<const float*>(lds + AUX16_OFF + ((t_idx & 1) * 4 + wave) * AUX_WAVE + 256 +
-                                                           (j * 16 + c16) * 4);
-          tl[j] = tok < N ? tj : __builtin_inff();
-        }
-        // first entry of the (token j = 0, list) list, in entries; token j adds j * lstride (host: fused_plan checks
-        // that every entry index fits 32 bits)
-        const uint32_t lbase0 = (uint32_t)(((tok0 + wn * 128 + c16) * p.nL + list) * FUSED_SLOTS);
-        const uint32_t lstride = 16u * (uint32_t)p.nL * FUSED_SLOTS;
-        uint2* q = reinterpret_cast<uint2*>(lds + QUEUE16_OFF) + wave * (QLANE16 * 64);
-        // byte cursor into this lane's queue: entry e of lane l sits at q[e * 64 + l]; a full queue keeps overwriting
-        // its last slot while the cursor runs on and reports the overflow
-        char* const qb = reinterpret_cast<char*>(q) + lane * 8;
-        constexpr uint32_t QLAST = (QLANE16 - 1) * 512;
-        unsigned long long cntp = 0ull;  // the eight list lengths of this lane, one byte each
-        bool q_over = false;
-        uint32_t qoff = 0;           // bytes: 512 per entry
-        uint32_t gm[2] = {0u, 0u};   // bit i * 8 + j: this lane had a hit in that group
-        const bool qflush = p.qflush != 0;  // wave-uniform (host: fused_plan)
-        if (!(dbg & 2))
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (i * 16 < lat_left) {
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {
-              // four token groups together: 16 reads, 8 max, 4 compares into SGPR pairs, THEN the four wave-uniform
-              // branches -- one VALU -> SALU dependency stall per four groups instead of one per group
-              float a[4][4];
-              unsigned long long hm[4];
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) a[jj][qq] = acc_read(acc[i][jh * 4 + jj][qq]);
-              }
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) {
-                // thresholds are positive, so a >= t  <=>  bits(a) >= bits(t) as SIGNED integers
-                const int mx = max(max(__float_as_int(a[jj][0]), __float_as_int(a[jj][1])),
-                                   max(__float_as_int(a[jj][2]), __float_as_int(a[jj][3])));
-                hm[jj] = __ballot(mx >= __float_as_int(tl[jh * 4 + jj]));
-              }
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) asm volatile("" : "+s"(hm[jj]));  // all four masks exist before the first branch
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) {
-                if (hm[jj] != 0ull) {
-                  uint32_t flag;  // 1 in the lanes with a hit (the mask is already an SGPR pair: one v_cndmask)
-                  asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(flag) : "s"(hm[jj]));
-                  const bf16x2_t p01 = {(__bf16)a[jj][0], (__bf16)a[jj][1]}, p23 = {(__bf16)a[jj][2], (__bf16)a[jj][3]};
-                  *reinterpret_cast<uint2*>(qb + (qoff < QLAST ? qoff : QLAST)) =
-                      make_uint2(__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23));
-                  qoff += flag << 9;
-                  gm[i >> 2] |= flag << ((i & 3) * 8 + jh * 4 + jj);
-                }
-              }
-              CLT_FENCE();
-            }
-          }
-          // the queue is turned into list entries after the last latent tile or -- when the host expects more than the
-          // queue's QLANE16 - 1 hit groups per lane and tile to be likely (latent shards) -- after every second one
-          if (!(i == 7 || (qflush && (i & 1)))) continue;
-          // ---- queue -> lists (rolled)
-          int nq = (int)(qoff >> 9);
-          q_over = q_over || nq > QLANE16 - 1;  // (slot QLANE16 - 1 is where writes go once the queue is full: not an entry)
-          nq = nq > QLANE16 - 1 ? QLANE16 - 1 : nq;
-#pragma unroll 1
-          for (int e = 0; __ballot(e < nq) != 0ull; ++e) {
-            if (e < nq) {
-              const uint2 ent = q[e * 64 + lane];
-              const int gi = gm[0] != 0u ? __builtin_ctz(gm[0]) : 32 + __builtin_ctz(gm[1]);  // the e-th set bit
-              if (gm[0] != 0u) gm[0] &= gm[0] - 1u;
-              else gm[1] &= gm[1] - 1u;
-              const uint32_t j = (uint32_t)gi & 7u, sh = j * 8u, pos0 = ((uint32_t)gi >> 3) * 4u;
-              float tj = tl[0];
-#pragma unroll
-              for (int jj = 1; jj < 8; ++jj) tj = j == (uint32_t)jj ? tl[jj] : tj;
-              // (threshold's bf16 value << 16), at least the smallest positive bf16: zeros carry nothing
-              const uint32_t vm = (__float_as_uint(tj) + 0x8000u) >> 16;
-              const int thr = (int)((vm < 1u ? 1u : vm) << 16);
-              const uint32_t lb = lbase0 + j * lstride;
-#pragma unroll
-              for (int qq = 0; qq < 4; ++qq) {
-                const uint32_t w = qq < 2 ? ent.x : ent.y;
-                const uint32_t vb = (qq & 1) ? (w & 0xffff0000u) : (w << 16);  // bf16 bits << 16
-                if ((int)vb >= thr) {
-                  const uint32_t c = (uint32_t)(cntp >> sh) & 255u;
-                  if (c < (uint32_t)FUSED_SLOTS && !(dbg & 1)) p.lists[lb + c] = vb | (pos0 + (uint32_t)qq);
-                  cntp += 1ull << sh;
-                }
-              }
-            }
-          }
-          qoff = 0;
-          gm[0] = gm[1] = 0u;
-          CLT_FENCE();
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int64_t tok = tok0 + wn * 128 + j * 16 + c16;
-          const uint32_t c = (uint32_t)(cntp >> (8 * j)) & 255u;  // > FUSED_SLOTS: the merge kernel reports the overflow
-          if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(q_over ? 255u : c);
-        }
       }
       ks = 0;
       if (++t_idx < my_tiles) {
@@ -629,13 +510,11 @@ void launch_pack_x(const FastArgs& a, void* xp, int* zero_ints, int n_zero, hipS
 // ahead, is then never more than one tile ahead, which is what the two aux areas allow); M a multiple of 16.
 bool gemm_fast16_ok(int64_t M, int kbytes) { return kbytes % (2 * ROWB) == 0 && kbytes >= PF * ROWB && (M & 15) == 0; }
 
-int launch_gemm_fast16(const FastArgs& a, int out_dtype, bool filter, int grid, hipStream_t st) {
-  if (filter)
-    hipLaunchKernelGGL((gemm_fast16_kernel<bf16_t, 1>), dim3(grid), dim3(NTHREADS), 0, st, a);
-  else if (out_dtype == CLT_BF16)
-    hipLaunchKernelGGL((gemm_fast16_kernel<bf16_t, 0>), dim3(grid), dim3(NTHREADS), 0, st, a);
+int launch_gemm_fast16(const FastArgs& a, int out_dtype, int grid, hipStream_t st) {
+  if (out_dtype == CLT_BF16)
+    hipLaunchKernelGGL((gemm_fast16_kernel<bf16_t>), dim3(grid), dim3(NTHREADS), 0, st, a);
   else
-    hipLaunchKernelGGL((gemm_fast16_kernel<float, 0>), dim3(grid), dim3(NTHREADS), 0, st, a);
+    hipLaunchKernelGGL((gemm_fast16_kernel<float>), dim3(grid), dim3(NTHREADS), 0, st, a);
   CLT_CHECK_LAUNCH("clt_encoder_gemm_relu");
   return CLT_OK;
 }

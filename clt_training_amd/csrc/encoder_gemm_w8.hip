@@ -25,18 +25,22 @@
 namespace clt {
 namespace {
 
+#ifndef CLT_ABL8  // compile-time ablations for tools/ (results are garbage): 4 = no LDS-DMA in the loop, 8 = no fragment
+#define CLT_ABL8 0  // reads, 16 = no certification wait, 32 = no barrier, 64 = waves 4-7 at s_setprio 1
+#endif
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 constexpr int NT8 = 512;     // threads: 8 waves, wave = (wm = wave >> 2: latent half, wn = wave & 3: token quarter)
 constexpr int PF8 = 4;       // stages the loader runs ahead of the multiplier (= ring slots: see encoder_gemm_fast16.hip)
 constexpr int STAGE8 = 2 * OP_BYTES;
 constexpr int AUX8_OFF = NSTAGE * STAGE8;
 constexpr int AUX8_WAVE = 256;  // a wave's aux piece: [0, 128) bias of latents 32 w .. + 31, [128, 256) tau of tokens 32 w .. + 31
-constexpr int QUEUE8_OFF = AUX8_OFF + 2 * 8 * AUX8_WAVE;
-constexpr int QLANE8 = 7;    // 8-byte hit-queue entries per lane between flushes (3.5 KiB per wave)
+constexpr int LDS8_BYTES = AUX8_OFF + 2 * 8 * AUX8_WAVE;  // 132 KiB: the ring and the aux pieces of two tiles
 constexpr int NDMA8 = 4;     // data LDS-DMAs per wave and stage: 2 W pieces, 2 x pieces
-static_assert(QUEUE8_OFF + 8 * QLANE8 * 64 * 8 <= 160 * 1024, "LDS");
+static_assert(LDS8_BYTES <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -72,15 +76,19 @@ template <int OFF>
 __device__ __forceinline__ void dma_m0(const char* sbase, uint32_t voff) {
   asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
-// the aux piece: lanes of `mask` only (every lane of the wave is active here: uniform control flow)
-__device__ __forceinline__ void dma_aux(const char* src, uint32_t lds_dst, unsigned long long mask) {
+// the aux piece: the bias chunks (lanes of mask_b, from base_b + voff) and the tau chunks (lanes of mask_t, from
+// base_t + voff); lane l lands at lds_dst + 16 l either way (every lane of the wave is active here: uniform control flow)
+__device__ __forceinline__ void dma_aux(const char* base_b, const char* base_t, uint32_t voff, uint32_t lds_dst,
+                                        unsigned long long mask_b, unsigned long long mask_t) {
   asm volatile(
-      "s_mov_b32 m0, %1\n\t"
-      "s_mov_b64 exec, %2\n\t"
-      "global_load_lds_dwordx4 %0, off\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b64 exec, %4\n\t"
+      "global_load_lds_dwordx4 %0, %1\n\t"
+      "s_mov_b64 exec, %5\n\t"
+      "global_load_lds_dwordx4 %0, %2\n\t"
       "s_mov_b64 exec, -1"
       :
-      : "v"(src), "s"(lds_dst), "s"(mask)
+      : "v"(voff), "s"(base_b), "s"(base_t), "s"(lds_dst), "s"(mask_b), "s"(mask_t)
       : "memory", "m0");
 }
 // All LDS reads of this wave have returned; every fragment passes through the statement, so no MFMA that consumes one
@@ -95,12 +103,17 @@ __device__ __forceinline__ void frag_wait(u32x4 (&A)[8], u32x4 (&B)[4]) {
 }
 
 __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[QUEUE8_OFF + 8 * QLANE8 * 64 * 8];
+  __shared__ __attribute__((aligned(1024))) char lds[LDS8_BYTES];
   const int ntt = p.ntt;
   const char* __restrict__ xb = p.x;
   const char* __restrict__ Wb = p.W;
   const char* __restrict__ bias = p.bias;
-  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt, dbg = p.dbg;
+  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt;
+#ifdef CLT_TUNING  // timing ablations (tools/): 2 = no scan, 8 = no list stores
+  const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
   const int64_t N = p.N, M = p.M;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
@@ -165,10 +178,11 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
   int ld_t = 0, ld_ks = 0, ld_slot = 0;
   const char* ldW = Wb;
   const char* ldX = xb;
-  const char* ldA = zero;  // per-lane source of the aux piece: bias chunk (lanes < nl <= 8) or tau chunk (lanes 8 .. 15)
-  uint32_t voffW[2], voffX[2];
+  const char* ldAb = zero;  // aux piece: the tile's bias table (or 16 zero bytes) ...
+  uint32_t ldA = 0;         // ... and the byte offset of this lane's bias chunk in it (lanes < nl <= 8) or of its tau chunk in
+  uint32_t voffW[2], voffX[2];  // p.tau (lanes 8 .. 15)
   const int nl = 32 * bias_esize / 16;  // lanes of the bias piece (this wave's 32 latents)
-  const unsigned long long aux_mask = __ballot(lane < nl || (lane >= 8 && lane < 16));
+  const unsigned long long aux_mask_b = __ballot(lane < nl), aux_mask_t = __ballot(lane >= 8 && lane < 16);
   const int ntt_layer = p.ntt_layer;
   const int ldx = ntt_layer ? (int)p.ldx_bytes : kbytes;  // bytes between consecutive token rows of x
   const char* __restrict__ xp = p.xp;                      // packed copy of x (fused path), or null
@@ -200,10 +214,10 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
                     : (uint32_t)((r < maxX ? r : maxX) * ldx + c * 16 + DMA_BIAS - q * 1024);
     }
     const int epc = 16 / bias_esize;
-    const int64_t lat = lat0 + 32 * wave + lane * epc;
-    ldA = (bt && lane < nl && lat + epc <= M) ? bt + lat * bias_esize : zero;
-    if (lane >= 8 && lane < 16)  // tau is padded to a multiple of 256 tokens
-      ldA = reinterpret_cast<const char*>(p.tau + tok0 + wave * 32 + (lane - 8) * 4);
+    const int64_t lat = lat0 + 32 * wave + lane * epc;  // (chunks past the end re-read the last one: never scanned)
+    ldAb = bt ? bt : zero;
+    ldA = bt ? (uint32_t)((lat + epc <= M ? lat : M - epc) * bias_esize) : 0u;
+    if (lane >= 8) ldA = (uint32_t)((tok0 + wave * 32 + (lane - 8) * 4) * 4);  // tau is padded to a multiple of 256 tokens
   };
   // LDS-DMA operation u of a stage: 0 = m0 for W, 1..2 W pieces, 3 = m0 for x, 4..5 x pieces, 6 aux piece (tile parity
   // ld_t & 1: the aux pieces of the running tile stay put while the loader is in the next one)
@@ -214,7 +228,8 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
     else if constexpr (u == 3) set_m0(stage_lds + OP_BYTES + wave * 2048);
     else if constexpr (u <= 5) dma_m0<(u - 4) * 1024>(ldX + (int64_t)(kb0 / ROWB) * xstep, voffX[u - 4]);
     else if (kb0 == 0)  // a tile's first stage (wave-uniform): the tile's aux piece; lane l lands at + 16 l
-      dma_aux(ldA, lds0 + AUX8_OFF + ((ld_t & 1) * 8 + wave) * AUX8_WAVE, aux_mask);
+      dma_aux(ldAb, reinterpret_cast<const char*>(p.tau), ldA, lds0 + AUX8_OFF + ((ld_t & 1) * 8 + wave) * AUX8_WAVE,
+              aux_mask_b, aux_mask_t);
   };
   auto loader_advance = [&]() {
     ld_slot = (ld_slot + 1) & 3;
@@ -243,6 +258,10 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
 
   f32x4 acc[8][4];
   u32x4 FA0[8], FB0[4], FA1[8], FB1[4];
+  // byte offset of this lane's list of token j = 0 (in the tile) from the tile's first list of this latent half; token
+  // j adds j * lstep
+  const uint32_t lvoff0 = (uint32_t)(((wn * 64 + c16) * p.nL + hq) << 6);
+  const uint32_t lstep = (uint32_t)p.nL << 10;
 
   // The bias enters as three extra K columns (encoder_gemm_fast.hip): A = (b_hi, b_mid, b_lo, 0...) of this lane's
   // latent, B = (1, 1, 1, 0...), both in the lanes of K chunk 0.
@@ -304,20 +323,28 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
       constexpr int i = t >> 2, j = t & 3;
       acc[i][j] = mfma16(Ac[i], Bc[j], acc[i][j]);
       CLT_FENCE();
-      if constexpr (t == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      if constexpr (t == 1) {
+        if constexpr ((CLT_ABL8 & 48) == 48) asm volatile("" ::: "memory");
+        else if constexpr (CLT_ABL8 & 16) asm volatile("s_barrier" ::: "memory");
+        else if constexpr (CLT_ABL8 & 32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      }
       constexpr int q = dma8_at(t), pc = read8_at(t);
-      if constexpr (q >= 0) {  // (the m0 write of an operand goes with its first piece)
+      if constexpr (q >= 0 && !(CLT_ABL8 & 4)) {  // (the m0 write of an operand goes with its first piece)
         if constexpr (q == 0) dma(std::integral_constant<int, 0>{}, ld_stage, kb0);
         if constexpr (q == 2) dma(std::integral_constant<int, 3>{}, ld_stage, kb0);
         dma(std::integral_constant<int, (q < 2 ? q + 1 : q + 2)>{}, ld_stage, kb0);
         if constexpr (q == 3) dma(std::integral_constant<int, 6>{}, ld_stage, kb0);
       }
-      if constexpr (pc >= 0) read_piece(std::integral_constant<int, pc>{}, sa, sb, An, Bn);
+      if constexpr (pc >= 0 && !(CLT_ABL8 & 8)) read_piece(std::integral_constant<int, pc>{}, sa, sb, An, Bn);
       CLT_FENCE();
     });
   };
   static_assert(2 * NDMA8 == 8, "the counted wait of kstep");
 
+  if constexpr (CLT_ABL8 & 64) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
   int ks = 0, t_idx = 0;
 #pragma unroll 1
   for (int s = 0; s < total; s += 2) {
@@ -334,15 +361,15 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
       const int64_t lat0 = (int64_t)lt_act * GEMM_TM, tok0 = (int64_t)cur_tt * GEMM_TN;
       // M is a multiple of 16 (host), so a 16-latent MFMA tile is inside or outside M as a whole: wave-uniform tests
       const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);
-      // ---- filter epilogue (the scheme of encoder_gemm_fast16.hip): an accumulator that reaches its token's threshold is
-      //      appended, as (bf16 bits << 16 | position in the list's 32 latents), to the private list of this (token,
-      //      latent tile, latent half, lane quarter); the list's length goes to counts.  Scan: per accumulator register
-      //      group (4 latents of one token) an integer max-of-4 read straight from the accumulator VGPRs + ONE compare;
-      //      the four token groups of a latent row are compared together and their masks pinned in SGPR pairs before the
-      //      four wave-uniform branches.  A group with a hit runs a short inline straight-line body: every lane writes
-      //      the group's four values, rounded to bf16, as ONE 8-byte entry at its lane-private LDS queue cursor; only
-      //      lanes with a hit advance the cursor and set the group's bit (i * 4 + j) in a per-lane mask.  A rolled loop
-      //      turns queue entries into list entries, testing each of the four values against the threshold's bf16 value.
+      // ---- filter epilogue.  Candidate lists are private to (token, latent tile, latent half, lane quarter) = the 32
+      //      latents of one lane and token (8 latent rows x 4), and a list has ONE 8-byte slot per latent row: the four
+      //      accumulators of a register group that holds a hit go there as four bf16 values, whatever the other three
+      //      are (the merge kernel tests each value itself).  So a list cannot overflow, nothing is queued or counted,
+      //      and the scan is: per group an integer max-of-4 read straight from the accumulator VGPRs + ONE compare; the
+      //      four token groups of a latent row are compared together and their masks pinned in SGPR pairs before the
+      //      four wave-uniform branches; a group with a hit converts its four values (two v_cvt_pk) and the lanes with
+      //      a hit store them (EXEC = the compare mask for the one store instruction) at tile base (SGPR) + lane
+      //      constant + 8 * row.  Which rows of a list are filled goes to `counts` as a bit mask per (token, list).
       const int list = (cur_lt * 2 + wm) * 4 + hq;
       float tl[4];
       const char* aux = lds + AUX8_OFF + (t_idx & 1) * 8 * AUX8_WAVE;
@@ -352,20 +379,11 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
         const float tj = *reinterpret_cast<const float*>(aux + (tt >> 5) * AUX8_WAVE + 128 + (tt & 31) * 4);
         tl[j] = tok0 + tt < N ? tj : __builtin_inff();
       }
-      // first entry of the (token j = 0, list) list, in entries; token j adds j * lstride (host: fused_plan checks
-      // that every entry index fits 32 bits)
-      const uint32_t lbase0 = (uint32_t)(((tok0 + wn * 64 + c16) * p.nL + list) * FUSED_SLOTS);
-      const uint32_t lstride = 16u * (uint32_t)p.nL * FUSED_SLOTS;
-      uint2* q = reinterpret_cast<uint2*>(lds + QUEUE8_OFF) + wave * (QLANE8 * 64);
-      // byte cursor into this lane's queue: entry e of lane l sits at q[e * 64 + l]; a full queue keeps overwriting
-      // its last slot while the cursor runs on and reports the overflow
-      char* const qb = reinterpret_cast<char*>(q) + lane * 8;
-      constexpr uint32_t QLAST = (QLANE8 - 1) * 512;
-      uint32_t cntp = 0u;  // the four list lengths of this lane, one byte each
-      bool q_over = false;
-      uint32_t qoff = 0;   // bytes: 512 per entry
-      uint32_t gm = 0u;    // bit i * 4 + j: this lane had a hit in that group
-      const bool qflush = p.qflush != 0;  // wave-uniform (host: fused_plan)
+      // slot (token, list, row): lists + ((token * nL + list) * 8 + row) * 8 bytes = tile base + lane constant + 8 row
+      const char* lbase = reinterpret_cast<const char*>(p.lists) + ((tok0 * p.nL + (cur_lt * 2 + wm) * 4) << 6);
+      uint32_t gm = 0u;  // bit 8 j + i: row i of this lane's list of token j is filled
+      uint32_t lv0 = lvoff0;  // (opaque: hipcc otherwise hoists every lvoff0 + j * lstep out of the tile loop and spills them)
+      asm volatile("" : "+v"(lv0));
       if (!(dbg & 2))
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -382,61 +400,29 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
           for (int jj = 0; jj < 4; ++jj) asm volatile("" : "+s"(hm[jj]));  // all four masks exist before the first branch
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
-            if (hm[jj] != 0ull) {
-              uint32_t flag;  // 1 in the lanes with a hit (the mask is already an SGPR pair: one v_cndmask)
-              asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(flag) : "s"(hm[jj]));
+            if (hm[jj] != 0ull && !(dbg & 8)) {
               const bf16x2_t p01 = {(__bf16)acc[i][jj][0], (__bf16)acc[i][jj][1]},
                              p23 = {(__bf16)acc[i][jj][2], (__bf16)acc[i][jj][3]};
-              *reinterpret_cast<uint2*>(qb + (qoff < QLAST ? qoff : QLAST)) =
-                  make_uint2(__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23));
-              qoff += flag << 9;
-              gm |= flag << (i * 4 + jj);
+              const u32x2 ent = {__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23)};
+              uint32_t flag;  // 1 in the lanes with a hit (the mask is already an SGPR pair: one v_cndmask)
+              asm volatile(
+                  "v_cndmask_b32_e64 %0, 0, 1, %1\n\t"
+                  "s_mov_b64 exec, %1\n\t"
+                  "global_store_dwordx2 %2, %3, %4 offset:%5\n\t"
+                  "s_mov_b64 exec, -1"
+                  : "=&v"(flag)
+                  : "s"(hm[jj]), "v"(lv0 + (uint32_t)jj * lstep), "v"(ent), "s"(lbase), "n"(i * 8)
+                  : "memory");
+              gm |= flag << (8 * jj + i);
             }
           }
           CLT_FENCE();
         }
-        // the queue is turned into list entries after the last latent row or -- when the host expects more than the
-        // queue's QLANE8 - 1 hit groups per lane and tile to be likely (latent shards) -- after every second one
-        if (!(i == 7 || (qflush && (i & 1)))) continue;
-        // ---- queue -> lists (rolled)
-        int nq = (int)(qoff >> 9);
-        q_over = q_over || nq > QLANE8 - 1;  // (slot QLANE8 - 1 is where writes go once the queue is full: not an entry)
-        nq = nq > QLANE8 - 1 ? QLANE8 - 1 : nq;
-#pragma unroll 1
-        for (int e = 0; __ballot(e < nq) != 0ull; ++e) {
-          if (e < nq) {
-            const uint2 ent = q[e * 64 + lane];
-            const int gi = __builtin_ctz(gm);  // the e-th set bit
-            gm &= gm - 1u;
-            const uint32_t j = (uint32_t)gi & 3u, sh = j * 8u, pos0 = ((uint32_t)gi >> 2) * 4u;
-            float tj = tl[0];
-#pragma unroll
-            for (int jj = 1; jj < 4; ++jj) tj = j == (uint32_t)jj ? tl[jj] : tj;
-            // (threshold's bf16 value << 16), at least the smallest positive bf16: zeros carry nothing
-            const uint32_t vm = (__float_as_uint(tj) + 0x8000u) >> 16;
-            const int thr = (int)((vm < 1u ? 1u : vm) << 16);
-            const uint32_t lb = lbase0 + j * lstride;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-              const uint32_t w = qq < 2 ? ent.x : ent.y;
-              const uint32_t vb = (qq & 1) ? (w & 0xffff0000u) : (w << 16);  // bf16 bits << 16
-              if ((int)vb >= thr) {
-                const uint32_t c = (cntp >> sh) & 255u;
-                if (c < (uint32_t)FUSED_SLOTS && !(dbg & 1)) p.lists[lb + c] = vb | (pos0 + (uint32_t)qq);
-                cntp += 1u << sh;
-              }
-            }
-          }
-        }
-        qoff = 0;
-        gm = 0u;
-        CLT_FENCE();
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t tok = tok0 + wn * 64 + j * 16 + c16;
-        const uint32_t c = (cntp >> (8 * j)) & 255u;  // > FUSED_SLOTS: the merge kernel reports the overflow
-        if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(q_over ? 255u : c);
+        if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(gm >> (8 * j));
       }
       ks = 0;
       if (++t_idx < my_tiles) {

@@ -74,7 +74,7 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 // The 16x16x32 build of the same kernel (encoder_gemm_fast16.hip) takes the shapes with K a multiple of 64 elements, at
 // least 128, and M a multiple of 16; launch_gemm_fast picks it by this predicate, so the launches of one call agree.
 bool gemm_fast16_ok(int64_t M, int kbytes);
-int launch_gemm_fast16(const FastArgs& a, int out_dtype, bool filter, int grid, hipStream_t st);
+int launch_gemm_fast16(const FastArgs& a, int out_dtype, int grid, hipStream_t st);
 // The filter pass on eight waves, two per SIMD (encoder_gemm_w8.hip): same shapes, same lists, bit-identical accumulators.
 int launch_gemm_w8_filter(const FastArgs& a, int grid, hipStream_t st);
 // xp[a.kbytes / 64][a.ntt * 256][64 B] <- a.x (a.N, a.kbytes, a.ntt and the stacked-layer fields must be set)
