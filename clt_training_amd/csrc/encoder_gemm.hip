@@ -402,7 +402,7 @@ extern "C" int clt_encode_topk_fwd(const void* x, const void* W, int in_dtype, c
   const int dbg = tuning_env("CLT_GEMM_DEBUG", 0);  // -DCLT_TUNING builds only; 32: never take the fused path
   if (!(dbg & (16 | 32)) && valid_dtype(in_dtype) && valid_dtype(out_dtype) && aligned16(x) && aligned16(W) &&
       (!bias || (valid_dtype(bias_dtype) && aligned16(bias))) && k >= 1 && k <= M) {
-    const FusedPlan pl = fused_plan(in_dtype, out_dtype, N, M, d, k);
+    const FusedPlan pl = fused_plan(in_dtype, out_dtype, N, M, d, k, num_cus());
     const size_t tail = fused_flag_bytes(N);
     if (pl.ok && pl.bytes <= need - tail) {
       char* ws = (char*)workspace;
@@ -432,7 +432,7 @@ extern "C" int clt_encode_topk_fwd_layers(const void* x, int64_t x_row_stride, i
   // what the stacked launch needs: the bf16 fused path, whole 256-token tiles per layer, panels that do not straddle
   // layers, 16-byte aligned x rows; anything else is for the caller to run layer by layer (clt_encode_topk_fwd)
   const int64_t es = dtype_size(in_dtype);
-  const FusedPlan pl = fused_plan(in_dtype, out_dtype, N, M, d, k);
+  const FusedPlan pl = fused_plan(in_dtype, out_dtype, N, M, d, k, num_cus());
   const size_t need = clt_encode_topk_workspace_bytes(N, M, out_dtype);
   const size_t tail = fused_flag_bytes(N);
   CLT_UNSUPPORTED(pl.ok && n_layers <= GEMM_MAX_LAYERS && N_l % (GEMM_TN * GEMM_PANEL) == 0 &&

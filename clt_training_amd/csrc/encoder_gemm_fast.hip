@@ -440,11 +440,9 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
                                                            const uint8_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ lists, int nL, int lt_S, int64_t N,
                                                            int64_t M, int k, int m, bf16_t* __restrict__ out_vals,
-                                                           int64_t* __restrict__ out_idx, int* __restrict__ flag, int l16) {
+                                                           int64_t* __restrict__ out_idx, int* __restrict__ flag) {
   constexpr int C = (R - S) * 64;
-  constexpr int NE_CAP = 512;  // non-empty list groups of a token held in LDS between two drains (4 KiB per wave)
   __shared__ u64 lds_q[4][C];
-  __shared__ uint32_t lds_ne[4][2 * NE_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
   if (tok >= N) return;
@@ -467,79 +465,7 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
   bool over = false;
   const uint8_t* crow = counts + tok * nL;
   const uint32_t* lrow = lists + tok * (int64_t)nL * FUSED_SLOTS;
-  if (l16) {
-    // lists of the eight-wave kernel (encoder_gemm_w8.hip): l = ((virtual tile * 2 + wm) * 4 + lane quarter u), 32 latents
-    // each, ONE 8-byte slot per latent row i (four bf16 values: latents 16 i + 4 u + 0 .. 3 of the half tile); counts[l]
-    // is the bit mask of the filled rows, and the four lists of one (tile, wm) = group g4 have their masks in one aligned
-    // 32-bit word (bit 8 u + i).  No list can overflow.
-    // Phase 1: the wave reads ALL its mask words at once (16-byte loads issued back to back: one memory round trip
-    // instead of one per 64 lists) and compacts the non-empty groups, as (g4, mask word), into LDS -- about 150 of 720
-    // at C2.  Phase 2: a lane takes one non-empty group per round and walks its filled slots, the next slot's load
-    // issued before the current one is offered.
-    const int nL4 = nL >> 2;
-    const uint4* crow16 = reinterpret_cast<const uint4*>(crow);  // nL % 8 == 0 and nL * tok: rows are 8-byte aligned ...
-    const uint32_t* crow4 = reinterpret_cast<const uint32_t*>(crow);
-    const uint2* srow = reinterpret_cast<const uint2*>(lists) + tok * (int64_t)nL * 8;
-    volatile uint32_t* ne = lds_ne[wave];  // [NE_CAP] group ids, then [NE_CAP] mask words
-    int n_ne = 0;
-    // phase 2 over the groups collected so far (called when the buffer could not take another round of 256 groups,
-    // and at the end)
-    auto drain = [&]() {
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      for (int r0 = 0; r0 < n_ne; r0 += 64) {
-        const bool have = r0 + lane < n_ne;
-        const int g4 = have ? (int)ne[r0 + lane] : 0;
-        uint32_t mask = have ? ne[NE_CAP + r0 + lane] : 0u;
-        const unsigned lat_base = (unsigned)lt_actual(g4 >> 1, LT_REST, lt_S) * 256u + (g4 & 1) * 128;
-        const uint2* grow = srow + (int64_t)g4 * 32;  // 4 lists x 8 slots
-        auto slot_of = [&](uint32_t mk) { return mk ? __builtin_ctz(mk) : 0; };
-        int b = slot_of(mask);
-        uint2 ent = mask ? grow[b] : make_uint2(0u, 0u);
-        while (__ballot(mask != 0u) != 0ull) {
-          const bool cur = mask != 0u;
-          const int bc = b;
-          const uint2 ec = ent;
-          mask &= mask - 1u;
-          b = slot_of(mask);
-          if (mask) ent = grow[b];  // (in flight while the four values below are offered)
-          // slot bc = 8 u + i: latents lat_base + 16 i + 4 u + qq
-          const unsigned col0 = lat_base + (unsigned)(bc & 7) * 16u + (unsigned)(bc >> 3) * 4u;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const uint32_t w = qq < 2 ? ec.x : ec.y;
-            const float v = __uint_as_float((qq & 1) ? (w & 0xffff0000u) : (w << 16));
-            ws.offer(cur && v >= ws.thr_val && v > 0.f, v, col0 + qq);
-          }
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // (the LDS reads above are done before the next round overwrites the buffer)
-      __builtin_amdgcn_wave_barrier();
-      n_ne = 0;
-    };
-    const bool al16 = ((uintptr_t)crow & 15) == 0;  // ... 16-byte aligned when nL % 16 == 0 or the token is even
-    for (int w0 = 0; w0 < nL4; w0 += 256) {  // 64 lanes x 4 words per round
-      if (n_ne > NE_CAP - 256) drain();      // (wave-uniform: n_ne counts ballots)
-      uint32_t cw[4];
-      const int wb = w0 + lane * 4;
-      if (al16 && wb + 4 <= nL4) {
-        const uint4 t = crow16[wb >> 2];
-        cw[0] = t.x, cw[1] = t.y, cw[2] = t.z, cw[3] = t.w;
-      } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cw[u] = wb + u < nL4 ? crow4[wb + u] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool nz = cw[u] != 0u;
-        const unsigned long long bm = __ballot(nz);
-        const int pos = n_ne + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
-        if (nz) ne[pos] = (uint32_t)(wb + u), ne[NE_CAP + pos] = cw[u];  // pos < n_ne + 256 <= NE_CAP
-        n_ne += __popcll(bm);
-      }
-    }
-    drain();
-  } else
+  {
   for (int l0 = 0; l0 < nL; l0 += 64) {
     const int l = l0 + lane;
     int c = l < nL ? (int)crow[l] : 0;
@@ -559,9 +485,125 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
       ws.offer(v >= ws.thr_val && v > 0.f, v, col);
     }
   }
+  }
   ws.flush();
   const float thr_m = bf16_bits_to_f32(svals[tok * k + m - 1]);
   if (__ballot(over) != 0ull || ws.thr_val < thr_m) {
+    if (lane == 0) atomicOr(flag + 1 + tok / GEMM_TN, 1);  // this token's 256-token tile goes through the fallback
+  }
+  ws.finalize();
+  write_out<S, R>(ws, out_vals, CLT_BF16, tok, out_idx, k);
+}
+
+// ---- candidate stream of the eight-wave filter kernel (encoder_gemm_w8.hip) -> per-token candidate lists.
+// One block per region (= one wave of the filter launch): every entry {4 bf16 values, token, first latent} goes to a
+// free slot of its token's list (the order of a list does not matter to the selection).  A region holds the entries of
+// the 64 tokens of one tile quarter, for a few token tiles, and the 16 regions that share those tokens are processed at
+// the same time: one global atomic per entry made every token a chain of ~170 same-address atomics (49 us for 1.4 M
+// entries).  So a block first counts its entries per token in LDS (a small open-addressing table keyed by token),
+// reserves each token's range with ONE global atomic, and then places the entries.
+// A region that overflowed has dropped entries of unknown tokens: every token tile is flagged for the exact fallback.
+constexpr int BUCKET_SLOTS = 1024;  // table slots per block (a power of two); more distinct tokens than fit go the slow way
+__device__ __forceinline__ int bucket_slot(uint32_t* keys, uint32_t tok, bool insert) {
+  uint32_t h = (tok * 2654435761u) >> 22;
+  for (int probe = 0; probe < BUCKET_SLOTS; ++probe) {
+    const uint32_t cur = insert ? atomicCAS(keys + h, 0xffffffffu, tok) : keys[h];
+    if (cur == tok || (insert && cur == 0xffffffffu)) return (int)h;
+    if (!insert && cur == 0xffffffffu) return -1;
+    h = (h + 1) & (BUCKET_SLOTS - 1);
+  }
+  return -1;  // table full
+}
+__global__ __launch_bounds__(256) void fused_bucket_kernel(const u32x4* __restrict__ stream,
+                                                           const int* __restrict__ scounts, int rcap, int tcap,
+                                                           int* __restrict__ tcnt, u32x4* __restrict__ tlists,
+                                                           int* __restrict__ flags, int ntt, int64_t N) {
+  __shared__ uint32_t keys[BUCKET_SLOTS];
+  __shared__ int lcnt[BUCKET_SLOTS], lbase[BUCKET_SLOTS];
+  const int region = blockIdx.x;
+  int n = scounts[region];
+  if (n > rcap) {
+    for (int t = threadIdx.x; t < ntt; t += blockDim.x) flags[1 + t] = 1;
+    n = rcap;
+  }
+  for (int h = threadIdx.x; h < BUCKET_SLOTS; h += blockDim.x) keys[h] = 0xffffffffu, lcnt[h] = 0;
+  __syncthreads();
+  const u32x4* src = stream + (int64_t)region * rcap;
+  // (a token >= N is never written by the filter kernel: a bound on what this kernel can touch all the same)
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const uint32_t tok = src[e].z;
+    if ((int64_t)tok >= N) continue;
+    const int h = bucket_slot(keys, tok, true);
+    if (h >= 0) atomicAdd(lcnt + h, 1);
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < BUCKET_SLOTS; h += blockDim.x) {
+    const int c = lcnt[h];
+    if (c > 0) lbase[h] = atomicAdd(tcnt + keys[h], c);
+    lcnt[h] = 0;  // (now the cursor inside the reserved range)
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const u32x4 v = src[e];
+    const uint32_t tok = v.z;
+    if ((int64_t)tok >= N) continue;
+    const int h = bucket_slot(keys, tok, false);
+    const int pos = h >= 0 ? lbase[h] + atomicAdd(lcnt + h, 1) : atomicAdd(tcnt + tok, 1);  // (table full: one by one)
+    if (pos < tcap) tlists[(int64_t)tok * tcap + pos] = v;
+  }
+}
+
+// Final selection of the fused path on the per-token lists: one wave per token merges the sample's top-k (pass A) with
+// the token's candidates under the same 64-bit key order as clt_topk_rows, and verifies as fused_select_kernel does.
+template <int S, int R>
+__global__ __launch_bounds__(256) void fused_select_stream_kernel(const uint16_t* __restrict__ svals,
+                                                                  const int64_t* __restrict__ sidx,
+                                                                  const int* __restrict__ tcnt,
+                                                                  const u32x4* __restrict__ tlists, int tcap, int lt_S,
+                                                                  int64_t N, int64_t M, int k, int m,
+                                                                  bf16_t* __restrict__ out_vals,
+                                                                  int64_t* __restrict__ out_idx, int* __restrict__ flag) {
+  constexpr int C = (R - S) * 64;
+  __shared__ u64 lds_q[4][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
+  if (tok >= N) return;
+  WaveSelect<S, R, (S <= 2)> ws;
+  ws.init(lds_q[wave], lane, k);
+  ws.set_bits(48, 32 - __clz((int)(M > 1 ? M - 1 : 1)));  // bf16 values, latent indices < M
+  int n = tcnt[tok];
+  const bool over = n > tcap;  // (wave-uniform)
+  n = over ? tcap : n;
+  const u32x4* lrow = tlists + tok * (int64_t)tcap;
+  const u32x4 none = {0u, 0u, 0u, 0u};
+  u32x4 ent = lane < n ? lrow[lane] : none;  // (in flight while the sample's entries are offered)
+  // the sample's best k: column c of the sample matrix is latent (c / 256) * S * 256 + c % 256
+  for (int e0 = 0; e0 < k; e0 += 64) {
+    const int e = e0 + lane;
+    float v = -1.f;
+    unsigned col = 0;
+    if (e < k) {
+      v = bf16_bits_to_f32(svals[tok * k + e]);
+      const int64_t c = sidx[tok * k + e];
+      col = (unsigned)((c >> 8) * lt_S * 256 + (c & 255));
+    }
+    ws.offer(v > 0.f, v, col);
+  }
+  if (ws.cnt > 0) ws.flush();  // the threshold is now the sample's k-th value
+  for (int e0 = 0; e0 < n; e0 += 64) {
+    const u32x4 cur = ent;
+    const bool have = e0 + lane < n;
+    if (e0 + 64 < n) ent = e0 + 64 + lane < n ? lrow[e0 + 64 + lane] : none;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const uint32_t w = qq < 2 ? cur.x : cur.y;
+      const float v = __uint_as_float((qq & 1) ? (w & 0xffff0000u) : (w << 16));
+      ws.offer(have && v >= ws.thr_val && v > 0.f, v, cur.w + (unsigned)qq);
+    }
+  }
+  ws.flush();
+  const float thr_m = bf16_bits_to_f32(svals[tok * k + m - 1]);
+  if (over || ws.thr_val < thr_m) {
     if (lane == 0) atomicOr(flag + 1 + tok / GEMM_TN, 1);  // this token's 256-token tile goes through the fallback
   }
   ws.finalize();
@@ -612,7 +654,7 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 }
 
 // ---- fused encode + top-k ------------------------------------------------------------------------------------
-FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k) {
+FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k, int cus) {
   FusedPlan pl = {};
   if (!gemm_fast_supported(in_dtype, N, M, d) || out_dtype != CLT_BF16 || k < 1 || k > 256) return pl;
   // Sample stride: pass A (store mode, ~1.7x the cost per tile of the filter mode, plus a row top-k over M / S columns)
@@ -662,29 +704,35 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   pl.nltB = (int)nltB;
   pl.ntt = (int)ntt;
   pl.l16 = gemm_fast16_ok(M, d * 2) && !(tuning_env("CLT_GEMM_DEBUG", 0) & 64);
-  pl.nL = (int)nltB * (pl.l16 ? 8 : 4);
-  // the filter kernels address list entries with 32 bits: over all tokens (32x32x16 kernel: entry index) or inside a
-  // token tile (eight-wave kernel: byte offset from the tile's first list)
+  pl.nL = (int)nltB * 4;  // (32x32x16 kernels: lists of 64 latents)
+  // the 32x32x16 filter kernel addresses list entries with 32 bits
   if (!pl.l16 && (int64_t)ntt * GEMM_TN * pl.nL * FUSED_SLOTS >= (1ll << 32)) return pl;
-  if (pl.l16 && ((int64_t)GEMM_TN * pl.nL << 6) >= (1ll << 32)) return pl;
   pl.lds = nltA * GEMM_TM;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
-  if (pl.l16) {
-    // eight-wave kernel: 8 slots of 8 bytes per list, written sparsely -- 2 bytes per non-sample latent, the size of the
-    // bf16 pre-activation matrix they replace.  The sample matrix is dead once its row top-k has run, before the filter
-    // pass writes the first slot (stream order): the lists lie over it.
-    const size_t lists_bytes = (size_t)N * pl.nL * 64, sample_bytes = (size_t)N * pl.lds * 2;
-    pl.off_pre_s = pl.off_lists = take(lists_bytes > sample_bytes ? lists_bytes : sample_bytes);
-  } else {
-    pl.off_pre_s = take((size_t)N * pl.lds * 2);
-    pl.off_lists = take((size_t)N * pl.nL * FUSED_SLOTS * 4);  // FUSED_SLOTS u32 entries per list
-  }
+  pl.off_pre_s = take((size_t)N * pl.lds * 2);
   pl.off_svals = take((size_t)N * k * 2);
   pl.off_sidx = take((size_t)N * k * 8);
   pl.off_tau = take((size_t)ntt * GEMM_TN * 4);
-  pl.off_counts = take((size_t)N * pl.nL);
-  pl.off_xp = take(pl.l16 ? (size_t)ntt * GEMM_TN * d * 2 : 0);  // packed x (16x16x32 kernels)
+  if (pl.l16) {
+    // Eight-wave filter kernel: 16-byte candidate entries in one stream region per wave, then per-token lists.  About
+    // m * S entries per token are expected whatever the data (that is what the sampled threshold fixes); regions and
+    // lists hold three times their expected share.  An overflowing list costs its token tile's fallback, an overflowing
+    // region every tile's.
+    const int64_t tilesB = nltB * ntt;
+    pl.nregions = (int)(tilesB < cus ? tilesB : cus) * 8;
+    const double per_tok = (double)pl.m * (double)S;
+    pl.rcap = (int)align_up((size_t)(3.0 * per_tok * (double)N / pl.nregions) + 128, 64);
+    pl.tcap = (int)align_up((size_t)(3.0 * per_tok) + 64, 64);
+    pl.off_xp = take((size_t)ntt * GEMM_TN * d * 2);  // packed x (16x16x32 kernels)
+    pl.off_stream = take((size_t)pl.nregions * pl.rcap * 16);
+    pl.off_scounts = take((size_t)pl.nregions * 4);
+    pl.off_tcnt = take((size_t)N * 4);
+    pl.off_tlists = take((size_t)N * pl.tcap * 16);
+  } else {
+    pl.off_counts = take((size_t)N * pl.nL);
+    pl.off_lists = take((size_t)N * pl.nL * FUSED_SLOTS * 4);
+  }
   pl.bytes = off;
   pl.ok = true;
   return pl;
@@ -721,7 +769,7 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
     return CLT_ERR_LAUNCH;
   }
   if (pl.l16) {  // pass A and pass B read x from a k-step-major copy (the rare fallback reads x in place)
-    launch_pack_x(a, ws + pl.off_xp, flag, 1 + pl.ntt, st);
+    launch_pack_x(a, ws + pl.off_xp, flag, 1 + pl.ntt, (int*)(ws + pl.off_tcnt), (int)N, st);
     a.xp = ws + pl.off_xp;
     a.xp_kstep_bytes = (int64_t)pl.ntt * GEMM_TN * ROWB;
   }
@@ -746,23 +794,44 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   pb.nlt = pl.nltB;
   pb.lt_mode = LT_REST;
   pb.tau = tau;
-  pb.lists = (uint32_t*)(ws + pl.off_lists);
-  pb.counts = (uint8_t*)(ws + pl.off_counts);
-  pb.nL = pl.nL;
-  pb.qflush = pl.qflush;
-  rc = launch_gemm_fast(pb, CLT_BF16, true, cus, st);
-  if (rc != CLT_OK) return rc;
-  // merge
   const dim3 grid((unsigned)((N + 3) / 4));
-  if (k <= 64)
-    hipLaunchKernelGGL((fused_select_kernel<1, 4>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag, pl.l16 ? 1 : 0);
-  else if (k <= 128)
-    hipLaunchKernelGGL((fused_select_kernel<2, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag, pl.l16 ? 1 : 0);
-  else
-    hipLaunchKernelGGL((fused_select_kernel<4, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL, pl.S,
-                       N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag, pl.l16 ? 1 : 0);
+  if (pl.l16) {
+    pb.stream = ws + pl.off_stream;
+    pb.stream_counts = (int*)(ws + pl.off_scounts);
+    pb.stream_rcap = pl.rcap;
+    pb.fb_flags = flag;
+    rc = launch_gemm_fast(pb, CLT_BF16, true, cus, st);  // (its grid: the pl.nregions / 8 of fused_plan)
+    if (rc != CLT_OK) return rc;
+    int* tcnt = (int*)(ws + pl.off_tcnt);
+    const u32x4* tlists = (const u32x4*)(ws + pl.off_tlists);
+    hipLaunchKernelGGL(fused_bucket_kernel, dim3(pl.nregions), dim3(256), 0, st, (const u32x4*)pb.stream,
+                       pb.stream_counts, pl.rcap, pl.tcap, tcnt, (u32x4*)(ws + pl.off_tlists), flag, pl.ntt, N);
+    if (k <= 64)
+      hipLaunchKernelGGL((fused_select_stream_kernel<1, 4>), grid, dim3(256), 0, st, svals, sidx, tcnt, tlists, pl.tcap,
+                         pl.S, N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+    else if (k <= 128)
+      hipLaunchKernelGGL((fused_select_stream_kernel<2, 8>), grid, dim3(256), 0, st, svals, sidx, tcnt, tlists, pl.tcap,
+                         pl.S, N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+    else
+      hipLaunchKernelGGL((fused_select_stream_kernel<4, 8>), grid, dim3(256), 0, st, svals, sidx, tcnt, tlists, pl.tcap,
+                         pl.S, N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+  } else {
+    pb.lists = (uint32_t*)(ws + pl.off_lists);
+    pb.counts = (uint8_t*)(ws + pl.off_counts);
+    pb.nL = pl.nL;
+    pb.qflush = pl.qflush;
+    rc = launch_gemm_fast(pb, CLT_BF16, true, cus, st);
+    if (rc != CLT_OK) return rc;
+    if (k <= 64)
+      hipLaunchKernelGGL((fused_select_kernel<1, 4>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL,
+                         pl.S, N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+    else if (k <= 128)
+      hipLaunchKernelGGL((fused_select_kernel<2, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL,
+                         pl.S, N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+    else
+      hipLaunchKernelGGL((fused_select_kernel<4, 8>), grid, dim3(256), 0, st, svals, sidx, pb.counts, pb.lists, pl.nL,
+                         pl.S, N, M, k, pl.m, (bf16_t*)out_vals, out_idx, flag);
+  }
   CLT_CHECK_LAUNCH("clt_encode_topk_fwd");
   // gated fallback (a list overflowed / a token failed verification): the flagged 256-token tiles the plain way, into
   // the same outputs.  The pre rows of those tiles land on the front of the workspace, over the lists (consumed by now).

@@ -483,9 +483,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
 // tiles with copies of the last row.  A 16-row LDS-DMA piece of x is then 1 KiB of consecutive bytes instead of 16
 // segments of 64 B in 16 rows: the wave that issues it is held ~24 instead of ~42 cycles (tools/dma_cost.hip).
 __global__ void pack_x_kernel(const char* __restrict__ x, int64_t ldx, int64_t x_layer_bytes, int64_t N_l, int64_t N,
-                              int64_t Npad, int nsteps, uint4* __restrict__ xp, int* __restrict__ zero_ints, int n_zero) {
+                              int64_t Npad, int nsteps, uint4* __restrict__ xp, int* __restrict__ zero_ints, int n_zero,
+                              int* __restrict__ zero2, int n_zero2) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < n_zero) zero_ints[g] = 0;  // the call's fallback flags and counters (launch_fused_encode_topk)
+  if (g < n_zero2) zero2[g] = 0;     // and the per-token candidate counts
   if (g >= Npad * nsteps * 4) return;
   const int c = (int)(g & 3);
   const int64_t t = (g >> 2) % Npad, ks = (g >> 2) / Npad;
@@ -496,14 +498,14 @@ __global__ void pack_x_kernel(const char* __restrict__ x, int64_t ldx, int64_t x
 
 }  // namespace
 
-void launch_pack_x(const FastArgs& a, void* xp, int* zero_ints, int n_zero, hipStream_t st) {
+void launch_pack_x(const FastArgs& a, void* xp, int* zero_ints, int n_zero, int* zero2, int n_zero2, hipStream_t st) {
   const int64_t Npad = (int64_t)a.ntt * GEMM_TN;
   const int nsteps = a.kbytes / ROWB;
   const int64_t n = Npad * nsteps * 4;
   hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.x,
                      a.ntt_layer ? a.ldx_bytes : (int64_t)a.kbytes, a.x_layer_bytes,
                      a.ntt_layer ? (int64_t)a.ntt_layer * GEMM_TN : (int64_t)0, a.N, Npad, nsteps, (uint4*)xp, zero_ints,
-                     n_zero);
+                     n_zero, zero2, n_zero2);
 }
 
 // K a multiple of 64 elements (the k loop is unrolled by two) and at least PF k-steps per tile (the loader, PF stages

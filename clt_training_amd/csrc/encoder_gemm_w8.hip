@@ -33,12 +33,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
+#ifndef CLT_PANEL8
+#define CLT_PANEL8 GEMM_PANEL
+#endif
+constexpr int PANEL8 = CLT_PANEL8;  // token tiles per L2 panel (a power of two)
+constexpr int PANEL8_LOG = PANEL8 == 16 ? 4 : PANEL8 == 8 ? 3 : PANEL8 == 4 ? 2 : PANEL8 == 2 ? 1 : -1;
+static_assert(PANEL8_LOG > 0 && GEMM_PANEL % PANEL8 == 0 || PANEL8 == 16, "panel");
 constexpr int NT8 = 512;     // threads: 8 waves, wave = (wm = wave >> 2: latent half, wn = wave & 3: token quarter)
 constexpr int PF8 = 4;       // stages the loader runs ahead of the multiplier (= ring slots: see encoder_gemm_fast16.hip)
 constexpr int STAGE8 = 2 * OP_BYTES;
 constexpr int AUX8_OFF = NSTAGE * STAGE8;
 constexpr int AUX8_WAVE = 256;  // a wave's aux piece: [0, 128) bias of latents 32 w .. + 31, [128, 256) tau of tokens 32 w .. + 31
-constexpr int LDS8_BYTES = AUX8_OFF + 2 * 8 * AUX8_WAVE;  // 132 KiB: the ring and the aux pieces of two tiles
+constexpr int QUEUE8_OFF = AUX8_OFF + 2 * 8 * AUX8_WAVE;
+constexpr int QCAP8 = 224;   // 16-byte entries in a wave's candidate queue (3.5 KiB per wave)
+constexpr int LDS8_BYTES = QUEUE8_OFF + 8 * QCAP8 * 16;  // 160 KiB: the ring, the aux pieces of two tiles, the queues
 constexpr int NDMA8 = 4;     // data LDS-DMAs per wave and stage: 2 W pieces, 2 x pieces
 static_assert(LDS8_BYTES <= 160 * 1024, "LDS");
 
@@ -128,7 +136,10 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
   const int xstart = xg < rr ? xg * (qt + 1) : rr * (qt + 1) + (xg - rr) * qt;
   const int xcount = qt + (xg < rr ? 1 : 0);
   const int my_tiles = bi < xcount ? uni((xcount - bi + nbx - 1) / nbx) : 0;
-  if (my_tiles == 0) return;
+  if (my_tiles == 0) {  // (cannot happen with the host's grid: at most one block per tile)
+    if (lane == 0) p.stream_counts[(int)blockIdx.x * 8 + wave] = 0;
+    return;
+  }
 
   const int nsteps = kbytes / ROWB;  // even and >= PF8 (host: gemm_fast16_ok)
   const int total = my_tiles * nsteps;
@@ -140,12 +151,12 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
     int pp, rem, pt, full;
   };
   auto pos_panel = [&](TilePos& c) {
-    const int left = ntt - c.pp * GEMM_PANEL;
-    c.pt = left < GEMM_PANEL ? left : GEMM_PANEL;
+    const int left = ntt - c.pp * PANEL8;
+    c.pt = left < PANEL8 ? left : PANEL8;
     c.full = nlt * c.pt;
   };
   auto pos_init = [&](TilePos& c, int id) {
-    const int fullp = nlt * GEMM_PANEL;
+    const int fullp = nlt * PANEL8;
     c.pp = uni(id / fullp);
     c.rem = uni(id - c.pp * fullp);
     pos_panel(c);
@@ -159,15 +170,14 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
     }
   };
   auto pos_get = [&](const TilePos& c, int& lt, int& tt) {
-    if (c.pt == GEMM_PANEL) {
-      lt = c.rem >> 3;
-      tt = c.pp * GEMM_PANEL + (c.rem & 7);
+    if (c.pt == PANEL8) {
+      lt = c.rem >> PANEL8_LOG;
+      tt = c.pp * PANEL8 + (c.rem & (PANEL8 - 1));
     } else {
       lt = uni(c.rem / c.pt);
-      tt = uni(c.pp * GEMM_PANEL + c.rem % c.pt);
+      tt = uni(c.pp * PANEL8 + c.rem % c.pt);
     }
   };
-  static_assert(GEMM_PANEL == 8, "pos_get shifts by 3");
   TilePos ld_pos, cur_pos;
   pos_init(ld_pos, xstart + bi);
   cur_pos = ld_pos;
@@ -214,9 +224,12 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
                     : (uint32_t)((r < maxX ? r : maxX) * ldx + c * 16 + DMA_BIAS - q * 1024);
     }
     const int epc = 16 / bias_esize;
-    const int64_t lat = lat0 + 32 * wave + lane * epc;  // (chunks past the end re-read the last one: never scanned)
-    ldAb = bt ? bt : zero;
-    ldA = bt ? (uint32_t)((lat + epc <= M ? lat : M - epc) * bias_esize) : 0u;
+    // (32-bit lane arithmetic: the 64-bit form is hoisted out of the tile loop by hipcc and spilled, and its reload
+    // waits for vmcnt(0) -- every LDS-DMA in flight -- once per tile)
+    const int lat_in = 32 * wave + lane * epc;                                     // latent in the tile
+    const int lat_max = (int)(M - lat0 < GEMM_TM ? M - lat0 : GEMM_TM) - epc;      // last whole chunk (M % 16 == 0)
+    ldAb = bt ? bt : zero;  // (chunks past the end re-read the last one: never scanned)
+    ldA = bt ? ((uint32_t)lat0 + (uint32_t)(lat_in <= lat_max ? lat_in : lat_max)) * (uint32_t)bias_esize : 0u;
     if (lane >= 8) ldA = (uint32_t)((tok0 + wave * 32 + (lane - 8) * 4) * 4);  // tau is padded to a multiple of 256 tokens
   };
   // LDS-DMA operation u of a stage: 0 = m0 for W, 1..2 W pieces, 3 = m0 for x, 4..5 x pieces, 6 aux piece (tile parity
@@ -258,10 +271,31 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
 
   f32x4 acc[8][4];
   u32x4 FA0[8], FB0[4], FA1[8], FB1[4];
-  // byte offset of this lane's list of token j = 0 (in the tile) from the tile's first list of this latent half; token
-  // j adds j * lstep
-  const uint32_t lvoff0 = (uint32_t)(((wn * 64 + c16) * p.nL + hq) << 6);
-  const uint32_t lstep = (uint32_t)p.nL << 10;
+  // ---- candidate queue (LDS, wave-private) and this wave's region of the candidate stream (global)
+  const uint32_t qaddr = lds0 + QUEUE8_OFF + wave * (QCAP8 * 16);
+  int qn = 0;  // entries in the queue (wave-uniform)
+  const int region = (int)blockIdx.x * 8 + wave;
+  const int rcap = p.stream_rcap;  // entries per region (a multiple of 64)
+  u32x4* const rbase = reinterpret_cast<u32x4*>(p.stream) + (int64_t)region * rcap;
+  int rn = 0;  // entries of this wave already in its region (wave-uniform); runs on past rcap: the bucket kernel reports it
+  auto flush_queue = [&]() {
+    if (dbg & 4) {  // (timing ablation: the queue is dropped, and so is its count -- the stream stays consistent)
+      qn = 0;
+      return;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's queue writes have landed (one wave's LDS operations complete in order)
+    // (the lane number afresh: at 256 registers hipcc otherwise keeps 16 * lane alive across the tile loop in scratch)
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    for (int e0 = 0; e0 < qn; e0 += 64) {
+      const int e = e0 + ln;
+      if (e < qn && rn + e < rcap) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(lds + QUEUE8_OFF + wave * (QCAP8 * 16) + e * 16);
+        rbase[rn + e] = v;  // (write-through and non-temporal forms were measured: no difference)
+      }
+    }
+    rn += qn;
+    qn = 0;
+  };
 
   // The bias enters as three extra K columns (encoder_gemm_fast.hip): A = (b_hi, b_mid, b_lo, 0...) of this lane's
   // latent, B = (1, 1, 1, 0...), both in the lanes of K chunk 0.
@@ -361,16 +395,16 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
       const int64_t lat0 = (int64_t)lt_act * GEMM_TM, tok0 = (int64_t)cur_tt * GEMM_TN;
       // M is a multiple of 16 (host), so a 16-latent MFMA tile is inside or outside M as a whole: wave-uniform tests
       const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);
-      // ---- filter epilogue.  Candidate lists are private to (token, latent tile, latent half, lane quarter) = the 32
-      //      latents of one lane and token (8 latent rows x 4), and a list has ONE 8-byte slot per latent row: the four
-      //      accumulators of a register group that holds a hit go there as four bf16 values, whatever the other three
-      //      are (the merge kernel tests each value itself).  So a list cannot overflow, nothing is queued or counted,
-      //      and the scan is: per group an integer max-of-4 read straight from the accumulator VGPRs + ONE compare; the
-      //      four token groups of a latent row are compared together and their masks pinned in SGPR pairs before the
-      //      four wave-uniform branches; a group with a hit converts its four values (two v_cvt_pk) and the lanes with
-      //      a hit store them (EXEC = the compare mask for the one store instruction) at tile base (SGPR) + lane
-      //      constant + 8 * row.  Which rows of a list are filled goes to `counts` as a bit mask per (token, list).
-      const int list = (cur_lt * 2 + wm) * 4 + hq;
+      // ---- filter epilogue.  A register group (4 consecutive latents of one token) that holds an accumulator at or
+      //      above its token's threshold becomes ONE 16-byte entry {4 bf16 values, token, first latent}; the merge side
+      //      tests each value itself.  Scan: per group an integer max-of-4 read straight from the accumulator VGPRs + ONE
+      //      compare; the four token groups of a latent row are compared together and their masks pinned in SGPR pairs
+      //      before the four wave-uniform branches.  A group with a hit converts its values (two v_cvt_pk) and the lanes
+      //      with a hit append their entries, COMPACTED (position = wave cursor + rank of the lane among the hits), to the
+      //      wave's queue in LDS: one ds_write_b128 under EXEC = the compare mask.  The queue leaves for this wave's own
+      //      region of the candidate stream in global memory as rows of 64 entries (1 KiB per store instruction) at the
+      //      end of a tile once it holds a full row, and at the end of the kernel -- a scattered store per hit group
+      //      (8 bytes into a per-token list) was measured at ~35 cycles of the CU's store path each, 90 us per call.
       float tl[4];
       const char* aux = lds + AUX8_OFF + (t_idx & 1) * 8 * AUX8_WAVE;
 #pragma unroll
@@ -379,11 +413,10 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
         const float tj = *reinterpret_cast<const float*>(aux + (tt >> 5) * AUX8_WAVE + 128 + (tt & 31) * 4);
         tl[j] = tok0 + tt < N ? tj : __builtin_inff();
       }
-      // slot (token, list, row): lists + ((token * nL + list) * 8 + row) * 8 bytes = tile base + lane constant + 8 row
-      const char* lbase = reinterpret_cast<const char*>(p.lists) + ((tok0 * p.nL + (cur_lt * 2 + wm) * 4) << 6);
-      uint32_t gm = 0u;  // bit 8 j + i: row i of this lane's list of token j is filled
-      uint32_t lv0 = lvoff0;  // (opaque: hipcc otherwise hoists every lvoff0 + j * lstep out of the tile loop and spills them)
-      asm volatile("" : "+v"(lv0));
+      uint32_t tokv = (uint32_t)(tok0 + wn * 64 + c16);      // token of this lane's group j = 0 (group j: + 16 j)
+      uint32_t latv = (uint32_t)(lat0 + wm * 128 + hq * 4);  // first latent of this lane's group in row 0 (row i: + 16 i)
+      asm volatile("" : "+v"(tokv), "+v"(latv));  // (opaque: hipcc otherwise hoists every tokv + 16 j / latv + 16 i and spills)
+      bool q_over = false;  // wave-uniform
       if (!(dbg & 2))
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -401,29 +434,35 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
             if (hm[jj] != 0ull && !(dbg & 8)) {
+              if (qn > QCAP8 - 64) {  // (no room for another group: this token tile goes through the exact fallback)
+                q_over = true;
+                continue;
+              }
               const bf16x2_t p01 = {(__bf16)acc[i][jj][0], (__bf16)acc[i][jj][1]},
                              p23 = {(__bf16)acc[i][jj][2], (__bf16)acc[i][jj][3]};
-              const u32x2 ent = {__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23)};
-              uint32_t flag;  // 1 in the lanes with a hit (the mask is already an SGPR pair: one v_cndmask)
+              const u32x4 ent = {__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23), tokv + 16u * jj,
+                                 latv + 16u * i};
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[jj] >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)hm[jj], 0u));
+              const uint32_t qa = qaddr + (((uint32_t)qn + rank) << 4);
               asm volatile(
-                  "v_cndmask_b32_e64 %0, 0, 1, %1\n\t"
-                  "s_mov_b64 exec, %1\n\t"
-                  "global_store_dwordx2 %2, %3, %4 offset:%5\n\t"
+                  "s_mov_b64 exec, %0\n\t"
+                  "ds_write_b128 %1, %2\n\t"
                   "s_mov_b64 exec, -1"
-                  : "=&v"(flag)
-                  : "s"(hm[jj]), "v"(lv0 + (uint32_t)jj * lstep), "v"(ent), "s"(lbase), "n"(i * 8)
+                  :
+                  : "s"(hm[jj]), "v"(qa), "v"(ent)
                   : "memory");
-              gm |= flag << (8 * jj + i);
+              qn += __builtin_popcountll(hm[jj]);
             }
           }
           CLT_FENCE();
         }
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t tok = tok0 + wn * 64 + j * 16 + c16;
-        if (tok < N) p.counts[tok * p.nL + list] = (uint8_t)(gm >> (8 * j));
-      }
+      // The queue is written out once it holds a full row of 64 entries (dense 1 KiB stores), so a tile can always add
+      // QCAP8 - 127 = 97 entries and usually 161 -- ten times the mean at the BASELINE shapes, twice that of a tp8 shard.
+if (qn >= 64) flush_queue();  // (cadences of 1, 4 and 8 tiles, all waves together, were measured: no difference)
+      if (q_over && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+        atomicOr(p.fb_flags + 1 + cur_tt, 1);
       ks = 0;
       if (++t_idx < my_tiles) {
         pos_next(cur_pos);
@@ -435,6 +474,8 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing fetches
+  flush_queue();
+  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) p.stream_counts[region] = rn;
 }
 
 }  // namespace

@@ -51,6 +51,13 @@ struct FastArgs {
   uint8_t* counts;
   int nL;
   int qflush;         // filter mode: turn the hit queue into list entries after every quarter tile, not once per tile
+  // Eight-wave filter kernel (encoder_gemm_w8.hip): candidates leave as 16-byte entries {4 bf16 values of 4 consecutive
+  // latents, token, first latent} in a stream with one region of stream_rcap entries per wave (region = 8 * block +
+  // wave); stream_counts[region] = entries the wave produced (more than stream_rcap: the excess was dropped).
+  void* stream;
+  int* stream_counts;
+  int stream_rcap;
+  int* fb_flags;      // the fused path's flag area (below): a wave whose queue could not take a group flags its token tile
   // Several layers in one launch (same N_l, M, d; each layer its own W and bias): the layers' tokens are stacked, token
   // tile tt belongs to layer tt / ntt_layer (ntt_layer = N_l / 256; 0 = one layer: W / bias above).  x row t of layer l
   // starts at x + l * x_layer_bytes + t * ldx_bytes (a [N_l, L * d] block of layer inputs side by side: ldx = L * d * 2,
@@ -78,8 +85,8 @@ int launch_gemm_fast16(const FastArgs& a, int out_dtype, int grid, hipStream_t s
 // The filter pass on eight waves, two per SIMD (encoder_gemm_w8.hip): same shapes, same lists, bit-identical accumulators.
 int launch_gemm_w8_filter(const FastArgs& a, int grid, hipStream_t st);
 // xp[a.kbytes / 64][a.ntt * 256][64 B] <- a.x (a.N, a.kbytes, a.ntt and the stacked-layer fields must be set)
-// and zero_ints[0, n_zero) <- 0 (n_zero <= the launch's thread count)
-void launch_pack_x(const FastArgs& a, void* xp, int* zero_ints, int n_zero, hipStream_t st);
+// and zero_ints[0, n_zero) <- 0, zero2[0, n_zero2) <- 0 (both counts <= the launch's thread count)
+void launch_pack_x(const FastArgs& a, void* xp, int* zero_ints, int n_zero, int* zero2, int n_zero2, hipStream_t st);
 
 // Fused encode + top-k without the pre-activation matrix:
 //   pass A  GEMM over every S-th latent tile, stored [N, lds], and clt_topk_rows over it: per token the best k of the
@@ -93,14 +100,19 @@ void launch_pack_x(const FastArgs& a, void* xp, int* zero_ints, int n_zero, hipS
 //           [1 + ntt .. 1 + 2 ntt) the compacted tile ids.
 struct FusedPlan {
   bool ok;
-  bool l16;         // lists of 32 latents, 8 per latent tile (the 16x16x32 kernel); else 64 latents, 4 per tile
+  bool l16;         // the 16x16x32 kernels: packed x, eight-wave filter pass with a candidate stream; else the 32x32x16
+                    // kernel with candidate lists of 64 latents, 4 per latent tile
   int S, nltA, nltB, ntt, nL;
   int m;            // rank of the sample value that serves as threshold (<= k)
   int qflush;       // see FastArgs
   int64_t lds, Ls;  // sample matrix: leading dimension and valid columns
-  size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, off_xp, bytes;
+  // eight-wave filter kernel: stream regions (one per wave of its launch), entries per region / per token list
+  int nregions, rcap, tcap;
+  size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, off_xp, off_stream, off_scounts, off_tcnt,
+      off_tlists, bytes;
 };
-FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k);
+// cus: the device's compute units (the filter launch's grid, and with it the number of stream regions, follows from it)
+FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k, int cus);
 // bytes of the flag area at the end of the clt_encode_topk_fwd workspace
 inline size_t fused_flag_bytes(int64_t N) {
   const int64_t ntt = (N + GEMM_TN - 1) / GEMM_TN;

@@ -13,7 +13,7 @@ run() {  # lib dbg
 import csv,sys
 out = []
 for r in csv.DictReader(open(sys.argv[1])):
-    if ('gemm_' in r['Name'] or 'fused_select' in r['Name']) and int(r['Calls']) == 12:
+    if ('gemm_' in r['Name'] or 'fused_' in r['Name'] or 'topk_rows' in r['Name']) and int(r['Calls']) == 12:
         out.append(f"{r['Name'][:48]} {float(r['AverageNs'])/1e3:.1f} us")
 print("; ".join(out))
 PY
