@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void fused_select_stream_kernel(const uint16_t
   const u32x4* lrow = tlists + tok * (int64_t)tcap;
   const u32x4 none = {0u, 0u, 0u, 0u};
   u32x4 ent = lane < n ? lrow[lane] : none;  // (in flight while the sample's entries are offered)
-  // the sample's best k: column c of the sample matrix is latent (c / 256) * S * 256 + c % 256
+  // the sample's best k: column c of the sample matrix is latent c % 16 of group (c / 16) S + S - 1 (grp_actual)
   for (int e0 = 0; e0 < k; e0 += 64) {
     const int e = e0 + lane;
     float v = -1.f;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void fused_select_stream_kernel(const uint16_t
     if (e < k) {
       v = bf16_bits_to_f32(svals[tok * k + e]);
       const int64_t c = sidx[tok * k + e];
-      col = (unsigned)((c >> 8) * lt_S * 256 + (c & 255));
+      col = (unsigned)grp_actual((int)(c >> 4), LT_GSAMPLE, lt_S) * 16u + (unsigned)(c & 15);
     }
     ws.offer(v > 0.f, v, col);
   }
@@ -640,6 +640,7 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
   const int grid = grid_for((int64_t)a.nlt * a.ntt, cus);
   if (grid <= 0) return CLT_OK;
   if (gemm_fast16_ok(a.M, a.kbytes) && !(a.dbg & 64)) {  // (-DCLT_TUNING builds: CLT_GEMM_DEBUG 64 = the 32x32x16 kernels)
+    if (a.ngroups <= 0) a.ngroups = (int)(a.M / 16);  // every group of W (M % 16 == 0 here)
     if (filter) return launch_gemm_w8_filter(a, grid, st);  // eight waves, slot-per-row candidate lists
     return launch_gemm_fast16(a, out_dtype, grid, st);
   }
@@ -667,12 +668,27 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   if (S > s_cap) S = s_cap;
   if (S < 2) return pl;
   const int64_t nlt = (M + GEMM_TM - 1) / GEMM_TM, ntt = (N + GEMM_TN - 1) / GEMM_TN;
-  const int64_t nltA = (nlt + S - 1) / S, nltB = nlt - nltA;
-  if (nltB < 1) return pl;
-  // valid columns of the sample matrix: only its last tile can be W's (partial) last tile
-  const int64_t lastA = (nltA - 1) * S;
-  const int64_t last_valid = (M - lastA * GEMM_TM) < GEMM_TM ? (M - lastA * GEMM_TM) : GEMM_TM;
-  pl.Ls = (nltA - 1) * GEMM_TM + last_valid;
+  pl.l16 = gemm_fast16_ok(M, d * 2) && !(tuning_env("CLT_GEMM_DEBUG", 0) & 64);
+  int64_t nltA, nltB;
+  if (pl.l16) {
+    // 16x16x32 kernels: the sample is every S-th GROUP of 16 latent rows (grp_actual, gemm_fast_dev.h), spread over all
+    // tiles; sample tiles and filter tiles are runs of 16 virtual groups
+    const int64_t G = M / 16;
+    pl.ngA = (int)(G / S);
+    pl.ngB = (int)(G - G / S);
+    nltA = (pl.ngA + 15) / 16;
+    nltB = (pl.ngB + 15) / 16;
+    pl.Ls = (int64_t)pl.ngA * 16;
+    // group offsets inside a tile are 32-bit byte offsets from the tile's first group: at most 17 S groups apart
+    if ((17 * S * 16 + 16) * (int64_t)d * 2 >= (1ll << 31)) return pl;
+  } else {
+    nltA = (nlt + S - 1) / S, nltB = nlt - nltA;
+    // valid columns of the sample matrix: only its last tile can be W's (partial) last tile
+    const int64_t lastA = (nltA - 1) * S;
+    const int64_t last_valid = (M - lastA * GEMM_TM) < GEMM_TM ? (M - lastA * GEMM_TM) : GEMM_TM;
+    pl.Ls = (nltA - 1) * GEMM_TM + last_valid;
+  }
+  if (nltA < 1 || nltB < 1) return pl;
   if (pl.Ls < k) return pl;
   pl.S = (int)S;
   // Threshold rank m <= k: the sample's m-th value admits about m * S candidates per token instead of k * S.  The
@@ -703,7 +719,6 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   pl.nltA = (int)nltA;
   pl.nltB = (int)nltB;
   pl.ntt = (int)ntt;
-  pl.l16 = gemm_fast16_ok(M, d * 2) && !(tuning_env("CLT_GEMM_DEBUG", 0) & 64);
   pl.nL = (int)nltB * 4;  // (32x32x16 kernels: lists of 64 latents)
   // the 32x32x16 filter kernel addresses list entries with 32 bits
   if (!pl.l16 && (int64_t)ntt * GEMM_TN * pl.nL * FUSED_SLOTS >= (1ll << 32)) return pl;
@@ -776,7 +791,8 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   // pass A: every S-th latent tile, stored, and its row top-k -> the token thresholds
   FastArgs pa = a;
   pa.nlt = pl.nltA;
-  pa.lt_mode = LT_SAMPLE;
+  pa.lt_mode = pl.l16 ? LT_GSAMPLE : LT_SAMPLE;
+  pa.ngroups = pl.ngA;
   pa.pre = ws + pl.off_pre_s;
   pa.ldp = pl.lds;
   int rc = launch_gemm_fast(pa, CLT_BF16, false, cus, st);
@@ -792,7 +808,8 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   // pass B: all other tiles, filtered against the thresholds
   FastArgs pb = a;
   pb.nlt = pl.nltB;
-  pb.lt_mode = LT_REST;
+  pb.lt_mode = pl.l16 ? LT_GREST : LT_REST;
+  pb.ngroups = pl.ngB;
   pb.tau = tau;
   const dim3 grid((unsigned)((N + 3) / 4));
   if (pl.l16) {
@@ -840,6 +857,7 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   pf.xp = nullptr;  // (its pre rows may land on the packed copy)
   pf.nlt = (int)((M + GEMM_TM - 1) / GEMM_TM);
   pf.lt_mode = LT_ALL;
+  pf.ngroups = 0;
   pf.pre = ws;
   pf.ldp = M;
   pf.gate = flag;

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
   const char* __restrict__ bias = p.bias;
   const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt, dbg = p.dbg;
   const int* __restrict__ tt_map = p.tt_map;
-  const int64_t N = p.N, M = p.M;
+  const int64_t N = p.N;
+  const int ngroups = p.ngroups;  // valid virtual groups of 16 latent rows (host: launch_gemm_fast)
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
   const int64_t xstep = xp ? p.xp_kstep_bytes : ROWB;      // bytes from one k-step of x to the next
   constexpr int DMA_BIAS = 3 * 1024;  // piece q is loaded with immediate q * 1024: lane offsets carry + 3072 - q * 1024 >= 0
   auto loader_tile = [&](int lt, int tt) {
-    const int64_t lat0 = (int64_t)lt_actual(lt, p.lt_mode, p.lt_S) * GEMM_TM, tok0 = (int64_t)tt * GEMM_TN;
+    const int64_t tok0 = (int64_t)tt * GEMM_TN;
     const char* Wt = Wb;
     const char* bt = bias;
     if (ntt_layer) {  // stacked layers: this token tile's layer picks the table, the bias and the x block
@@ -233,21 +234,27 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
       ldX = xb + tok0 * kbytes - DMA_BIAS;
     }
     if (xp) ldX = xp + tok0 * ROWB - DMA_BIAS;  // packed copy [k-step][token][64 B]: a piece is 1 KiB of consecutive bytes
-    ldW = Wt + lat0 * kbytes - DMA_BIAS;
-    // rows past the end re-read the last row (their products are never stored)
-    const int maxW = (int)(M - 1 - lat0 < GEMM_TM ? M - 1 - lat0 : GEMM_TM);
+    // W rows come in groups of 16 (grp_actual): piece q of this wave is virtual group 16 lt + 4 wave + q; groups past the
+    // end re-read the last one (their products are never stored).  Offsets are relative to the tile's first group.
+    const int vg_last = ngroups - 1;
+    const int g_first = grp_actual(lt * 16 < vg_last ? lt * 16 : vg_last, p.lt_mode, p.lt_S);
+    ldW = Wt + (int64_t)g_first * 16 * kbytes - DMA_BIAS;
     const int maxX = (int)(N - 1 - tok0 < GEMM_TN ? N - 1 - tok0 : GEMM_TN);  // (stacked layers: N_l % 256 == 0)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = (wave * 4 + q) * 16 + (lane >> 2);  // wave w stages rows 64 w .. 64 w + 63 of either operand
       const int c = (lane & 3) ^ ((0 - (r >> 2)) & 3);  // this kernel's bank swizzle (see the fragment addresses)
-      voffW[q] = (uint32_t)((r < maxW ? r : maxW) * kbytes + c * 16 + DMA_BIAS - q * 1024);
+      const int vg = lt * 16 + wave * 4 + q;
+      const int g_rel = uni(grp_actual(vg < vg_last ? vg : vg_last, p.lt_mode, p.lt_S) - g_first);
+      voffW[q] = (uint32_t)((g_rel * 16 + (lane >> 2)) * kbytes + c * 16 + DMA_BIAS - q * 1024);
       voffX[q] = xp ? (uint32_t)(r * ROWB + c * 16 + DMA_BIAS - q * 1024)  // (padding rows exist in the packed copy)
                     : (uint32_t)((r < maxX ? r : maxX) * ldx + c * 16 + DMA_BIAS - q * 1024);
     }
+    // bias chunk of lane l < nl: latents 64 wave + l epc .. of the tile, i.e. group 4 wave + (l epc >> 4), offset (l epc) & 15
     const int epc = 16 / bias_esize;
-    const int64_t lat = lat0 + 64 * wave + lane * epc;
-    ldA = (bt && lat + epc <= M) ? bt + lat * bias_esize : zero;
+    const int vgb = lt * 16 + wave * 4 + ((lane * epc) >> 4);
+    const int64_t lat = (int64_t)grp_actual(vgb < vg_last ? vgb : vg_last, p.lt_mode, p.lt_S) * 16 + ((lane * epc) & 15);
+    ldA = (bt && lane < nl) ? bt + lat * bias_esize : zero;
   };
   // LDS-DMA operation u of a stage: 0 = m0 for W, 1..4 W pieces, 5 = m0 for x, 6..9 x pieces, 10 aux piece (tile parity
   // ld_t & 1: the aux pieces of the running tile stay put while the loader is in the next one)
@@ -403,10 +410,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
     step_pair(std::integral_constant<int, 0>{});
 
     if (last_k) {
-      const int lt_act = lt_actual(cur_lt, p.lt_mode, p.lt_S);
-      const int64_t lat0 = (int64_t)lt_act * GEMM_TM, tok0 = (int64_t)cur_tt * GEMM_TN;
-      // M is a multiple of 16 (host), so a 16-latent MFMA tile is inside or outside M as a whole: wave-uniform tests
-      const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);
+      const int64_t tok0 = (int64_t)cur_tt * GEMM_TN;
+      // a 16-latent MFMA tile is one group: inside or outside the valid (virtual) groups as a whole -- wave-uniform tests
+      const int g_left = ngroups - (cur_lt * 16 + wm * 8);
+      const int lat_left = g_left < 8 ? (g_left > 0 ? g_left * 16 : 0) : 128;
       {
         // ---- store epilogue: ReLU, one rounding.  bf16: each 16-token x 128-latent block goes through a wave-private
         //      staging area in LDS (row = token, 256 B; 16-byte chunk c of row r at position c ^ r: the 8-byte writes of

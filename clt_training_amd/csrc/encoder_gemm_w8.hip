@@ -122,7 +122,8 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
 #else
   constexpr int dbg = 0;
 #endif
-  const int64_t N = p.N, M = p.M;
+  const int64_t N = p.N;
+  const int ngroups = p.ngroups;  // valid virtual groups of 16 latent rows (host: launch_gemm_fast)
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
   const int64_t xstep = xp ? p.xp_kstep_bytes : ROWB;      // bytes from one k-step of x to the next
   constexpr int DMA_BIAS = 1024;  // piece q is loaded with immediate q * 1024: lane offsets carry + 1024 - q * 1024 >= 0
   auto loader_tile = [&](int lt, int tt) {
-    const int64_t lat0 = (int64_t)lt_actual(lt, p.lt_mode, p.lt_S) * GEMM_TM, tok0 = (int64_t)tt * GEMM_TN;
+    const int64_t tok0 = (int64_t)tt * GEMM_TN;
     const char* Wt = Wb;
     const char* bt = bias;
     if (ntt_layer) {  // stacked layers: this token tile's layer picks the table, the bias and the x block
@@ -211,25 +212,30 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
       ldX = xb + tok0 * kbytes - DMA_BIAS;
     }
     if (xp) ldX = xp + tok0 * ROWB - DMA_BIAS;  // packed copy [k-step][token][64 B]: a piece is 1 KiB of consecutive bytes
-    ldW = Wt + lat0 * kbytes - DMA_BIAS;
-    // rows past the end re-read the last row (their products are never stored)
-    const int maxW = (int)(M - 1 - lat0 < GEMM_TM ? M - 1 - lat0 : GEMM_TM);
+    // W rows come in groups of 16 (grp_actual, gemm_fast_dev.h): piece q of this wave is virtual group 16 lt + 2 wave + q;
+    // groups past the end re-read the last one (never scanned).  Offsets are relative to the tile's first group.
+    const int vg_last = ngroups - 1;
+    const int g_first = grp_actual(lt * 16 < vg_last ? lt * 16 : vg_last, p.lt_mode, p.lt_S);
+    ldW = Wt + (int64_t)g_first * 16 * kbytes - DMA_BIAS;
     const int maxX = (int)(N - 1 - tok0 < GEMM_TN ? N - 1 - tok0 : GEMM_TN);  // (stacked layers: N_l % 256 == 0)
+    int g_act[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int r = (wave * 2 + q) * 16 + (lane >> 2);  // wave w stages rows 32 w .. 32 w + 31 of either operand
       const int c = (lane & 3) ^ ((0 - (r >> 2)) & 3);  // the bank swizzle of encoder_gemm_fast16.hip
-      voffW[q] = (uint32_t)((r < maxW ? r : maxW) * kbytes + c * 16 + DMA_BIAS - q * 1024);
+      const int vg = lt * 16 + wave * 2 + q;
+      g_act[q] = uni(grp_actual(vg < vg_last ? vg : vg_last, p.lt_mode, p.lt_S));
+      voffW[q] = (uint32_t)(((g_act[q] - g_first) * 16 + (lane >> 2)) * kbytes + c * 16 + DMA_BIAS - q * 1024);
       voffX[q] = xp ? (uint32_t)(r * ROWB + c * 16 + DMA_BIAS - q * 1024)  // (padding rows exist in the packed copy)
                     : (uint32_t)((r < maxX ? r : maxX) * ldx + c * 16 + DMA_BIAS - q * 1024);
     }
+    // bias chunk of lane l < nl: latents 32 wave + l epc .. of the tile = group 2 wave + (l epc >> 4), offset (l epc) & 15
+    // (32-bit lane arithmetic: a 64-bit form is hoisted out of the tile loop by hipcc and spilled, and its reload waits
+    // for vmcnt(0) -- every LDS-DMA in flight -- once per tile)
     const int epc = 16 / bias_esize;
-    // (32-bit lane arithmetic: the 64-bit form is hoisted out of the tile loop by hipcc and spilled, and its reload
-    // waits for vmcnt(0) -- every LDS-DMA in flight -- once per tile)
-    const int lat_in = 32 * wave + lane * epc;                                     // latent in the tile
-    const int lat_max = (int)(M - lat0 < GEMM_TM ? M - lat0 : GEMM_TM) - epc;      // last whole chunk (M % 16 == 0)
-    ldAb = bt ? bt : zero;  // (chunks past the end re-read the last one: never scanned)
-    ldA = bt ? ((uint32_t)lat0 + (uint32_t)(lat_in <= lat_max ? lat_in : lat_max)) * (uint32_t)bias_esize : 0u;
+    const int lb = lane * epc;
+    ldAb = bt ? bt : zero;
+    ldA = bt ? (uint32_t)((lb < 16 ? g_act[0] : g_act[1]) * 16 + (lb & 15)) * (uint32_t)bias_esize : 0u;
     if (lane >= 8) ldA = (uint32_t)((tok0 + wave * 32 + (lane - 8) * 4) * 4);  // tau is padded to a multiple of 256 tokens
   };
   // LDS-DMA operation u of a stage: 0 = m0 for W, 1..2 W pieces, 3 = m0 for x, 4..5 x pieces, 6 aux piece (tile parity
@@ -391,10 +397,23 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
     loader_advance();
 
     if (last_k) {
-      const int lt_act = lt_actual(cur_lt, p.lt_mode, p.lt_S);
-      const int64_t lat0 = (int64_t)lt_act * GEMM_TM, tok0 = (int64_t)cur_tt * GEMM_TN;
-      // M is a multiple of 16 (host), so a 16-latent MFMA tile is inside or outside M as a whole: wave-uniform tests
-      const int lat_left = (int)(M - lat0 - wm * 128 < 128 ? M - lat0 - wm * 128 : 128);
+      const int64_t tok0 = (int64_t)cur_tt * GEMM_TN;
+      // a 16-latent MFMA row tile is one group: inside or outside the valid (virtual) groups as a whole -- wave-uniform tests
+      const int vg0 = cur_lt * 16 + wm * 8;  // virtual group of row tile i = 0
+      const int g_left = ngroups - vg0;
+      const int lat_left = g_left < 8 ? (g_left > 0 ? g_left * 16 : 0) : 128;
+      // actual groups of the eight row tiles: v -> v + v / (S - 1) (LT_GREST) from one division, then by counting
+      int g_row[8];
+      {
+        const bool rest = p.lt_mode == LT_GREST;
+        const int sm1 = rest ? p.lt_S - 1 : 0x7fffffff;
+        int qd = rest ? uni(vg0 / sm1) : 0, rem = rest ? vg0 - qd * sm1 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          g_row[i] = vg0 + i + qd;
+          if (++rem == sm1) rem = 0, ++qd;
+        }
+      }
       // ---- filter epilogue.  A register group (4 consecutive latents of one token) that holds an accumulator at or
       //      above its token's threshold becomes ONE 16-byte entry {4 bf16 values, token, first latent}; the merge side
       //      tests each value itself.  Scan: per group an integer max-of-4 read straight from the accumulator VGPRs + ONE
@@ -414,8 +433,8 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
         tl[j] = tok0 + tt < N ? tj : __builtin_inff();
       }
       uint32_t tokv = (uint32_t)(tok0 + wn * 64 + c16);      // token of this lane's group j = 0 (group j: + 16 j)
-      uint32_t latv = (uint32_t)(lat0 + wm * 128 + hq * 4);  // first latent of this lane's group in row 0 (row i: + 16 i)
-      asm volatile("" : "+v"(tokv), "+v"(latv));  // (opaque: hipcc otherwise hoists every tokv + 16 j / latv + 16 i and spills)
+      uint32_t latv = (uint32_t)(hq * 4);  // first latent of this lane's register group inside its 16-latent row tile
+      asm volatile("" : "+v"(tokv), "+v"(latv));  // (opaque: hipcc otherwise hoists every tokv + 16 j / latv + ... and spills)
       bool q_over = false;  // wave-uniform
       if (!(dbg & 2))
 #pragma unroll
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
               const bf16x2_t p01 = {(__bf16)acc[i][jj][0], (__bf16)acc[i][jj][1]},
                              p23 = {(__bf16)acc[i][jj][2], (__bf16)acc[i][jj][3]};
               const u32x4 ent = {__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23), tokv + 16u * jj,
-                                 latv + 16u * i};
+                                 latv + 16u * (uint32_t)g_row[i]};
               const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[jj] >> 32),
                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)hm[jj], 0u));
               const uint32_t qa = qaddr + (((uint32_t)qn + rank) << 4);

@@ -11,7 +11,7 @@ constexpr int GEMM_PANEL = 8;  // token tiles per L2 panel
 constexpr int FUSED_SLOTS = 8; // entries per candidate list (64 latents of one token; 32 with the 16x16x32 kernel)
 constexpr int GEMM_MAX_LAYERS = 16;
 
-enum { LT_ALL = 0, LT_SAMPLE = 1, LT_REST = 2 };
+enum { LT_ALL = 0, LT_SAMPLE = 1, LT_REST = 2, LT_GSAMPLE = 3, LT_GREST = 4 };  // (see grp_actual, gemm_fast_dev.h)
 
 struct TileCoord {
   int64_t lat0, tok0;
@@ -46,6 +46,7 @@ struct FastArgs {
   int kbytes;
   int nlt, ntt;
   int lt_mode, lt_S;
+  int ngroups;        // 16x16x32 kernels: valid virtual groups of 16 latent rows (0: M / 16, every group of W)
   const float* tau;
   uint32_t* lists;
   uint8_t* counts;
@@ -108,6 +109,7 @@ struct FusedPlan {
   int64_t lds, Ls;  // sample matrix: leading dimension and valid columns
   // eight-wave filter kernel: stream regions (one per wave of its launch), entries per region / per token list
   int nregions, rcap, tcap;
+  int ngA, ngB;     // 16x16x32 kernels: groups of 16 latent rows in the sample / in the filter pass
   size_t off_pre_s, off_svals, off_sidx, off_tau, off_counts, off_lists, off_xp, off_stream, off_scounts, off_tcnt,
       off_tlists, bytes;
 };

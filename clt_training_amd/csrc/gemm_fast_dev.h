@@ -76,5 +76,18 @@ __host__ __device__ __forceinline__ int lt_actual(int v, int mode, int S) {
   return v;
 }
 
+// The 16x16x32 kernels (encoder_gemm_fast16.hip, encoder_gemm_w8.hip) address W in GROUPS of 16 latent rows -- one
+// group is one LDS-DMA piece and one MFMA row tile -- and a latent tile is 16 consecutive VIRTUAL groups:
+//   LT_ALL      virtual group v = group v of W;
+//   LT_GSAMPLE  the sample of the fused encode + top-k: every S-th group of W, v -> v S + S - 1;
+//   LT_GREST    all the others, v -> v + v / (S - 1).
+// Sampling ROW GROUPS inside every 256-row tile (not every S-th tile, as the 32x32x16 kernel does) keeps the sample
+// representative when the latents of a tile fire together -- trained dictionaries are correlated like that.
+__host__ __device__ __forceinline__ int grp_actual(int v, int mode, int S) {
+  if (mode == LT_GSAMPLE) return v * S + S - 1;
+  if (mode == LT_GREST) return v + v / (S - 1);
+  return v;
+}
+
 }  // namespace
 }  // namespace clt

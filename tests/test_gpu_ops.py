@@ -608,6 +608,30 @@ def test_fused_encode_topk_stays_on_the_fused_path(ops, N, M, d, k):
     assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
 
 
+@pytest.mark.parametrize("rho", [0.25, 0.5])
+def test_fused_encode_topk_holds_on_a_tile_correlated_dictionary(ops, rho):
+    """The other behaviour guard: a 'trained-like' dictionary (tools/bench_fused.py: Zipf firing frequencies, a few
+    latents active on more than half of the tokens, the latents of a 256-row tile sharing a direction with strength rho).
+    With the sample drawn as every S-th TILE a token aligned with a tile's direction never showed up in the sample and
+    31 of 32 token tiles went through the fallback at rho = 0.25; sampled as every S-th 16-row GROUP inside every tile
+    (grp_actual, csrc/gemm_fast_dev.h) the threshold sees every tile, and no candidate list can overflow any more."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from tools.bench_fused import dictionary
+
+    N, M, d, k = 2048, 98304, 768, 32
+    gx = torch.Generator(device=DEV).manual_seed(12345)
+    x = (torch.randn(N, d, device=DEV, generator=gx) + 0.1 * torch.randn(d, device=DEV, generator=gx)).bfloat16()
+    W, b = dictionary("hostile", M, d, rho)
+    v, i = ops.encode_topk(x, W, b, k)
+    flagged, tiles = ops.encode_topk_fallback_tiles(x, M)
+    assert tiles == N // 256 and flagged <= 1, (flagged, tiles)
+    v_ref, i_ref = _plain_encode_topk(ops, x, W, b, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+
+
 # --------------------------------------------------------------------------- FVU
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("masked", [False, True])
