@@ -375,12 +375,14 @@ extern "C" int clt_encoder_gemm_relu(const void* x, const void* W, int in_dtype,
 }
 
 // Workspace: the pre-activation matrix of the plain path (which is also the fused path's fallback), with the
-// fused path's buffers laid over it -- its candidate lists alone are 15/16 of that size, so an eighth is added for the
-// packed input, the sample's top-k and the list masks (a shape whose buffers still do not fit takes the plain path) --
-// and a tail that holds the fallback flags (gemm_fast.h).
+// fused path's buffers laid over it (sample matrix, packed input, candidate stream and per-token candidate lists: a
+// few hundred MB at the BASELINE shapes, but comparable to the matrix itself for a narrow dictionary -- hence the
+// margin; a shape whose buffers still do not fit takes the plain path), and a tail that holds the fallback flags
+// (gemm_fast.h).
 static size_t encode_topk_body_bytes(int64_t N, int64_t M, int out_dtype) {
   const size_t pre = (size_t)N * (size_t)M * dtype_size(out_dtype);
-  return align_up(pre + pre / 8, 256);
+  const size_t extra = pre / 8 > (size_t)N * 8192 ? pre / 8 : (size_t)N * 8192;  // (narrow dictionaries: 8 KiB per token)
+  return align_up(pre + extra, 256);
 }
 extern "C" size_t clt_encode_topk_workspace_bytes(int64_t N, int64_t M, int out_dtype) {
   if (N <= 0 || M <= 0) return 4096 + 256;

@@ -731,13 +731,14 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
   pl.off_tau = take((size_t)ntt * GEMM_TN * 4);
   if (pl.l16) {
     // Eight-wave filter kernel: 16-byte candidate entries in one stream region per wave, then per-token lists.  About
-    // m * S entries per token are expected whatever the data (that is what the sampled threshold fixes); regions and
-    // lists hold three times their expected share.  An overflowing list costs its token tile's fallback, an overflowing
-    // region every tile's.
+    // m * S entries per token are expected whatever the data (that is what the sampled threshold fixes).  An overflowing
+    // list costs its token tile's fallback, an overflowing region every tile's.
     const int64_t tilesB = nltB * ntt;
     pl.nregions = (int)(tilesB < cus ? tilesB : cus) * 8;
     const double per_tok = (double)pl.m * (double)S;
-    pl.rcap = (int)align_up((size_t)(3.0 * per_tok * (double)N / pl.nregions) + 128, 64);
+    // (a region sums thousands of (token, tile) pairs: 1.5 x its expected share + 256 is far out; a token's own count
+    // follows the sampled threshold's rank-m statistic -- Gamma(m) -- and gets 3 x)
+    pl.rcap = (int)align_up((size_t)(1.5 * per_tok * (double)N / pl.nregions) + 256, 64);
     pl.tcap = (int)align_up((size_t)(3.0 * per_tok) + 64, 64);
     pl.off_xp = take((size_t)ntt * GEMM_TN * d * 2);  // packed x (16x16x32 kernels)
     pl.off_stream = take((size_t)pl.nregions * pl.rcap * 16);
