@@ -2,8 +2,10 @@
 against the single-process fp64 oracle:
 
   c2  GPT-2 CLT width      d=768,  k=32,  M=12288, L=3, cross 3, skip + post_encoder_scale          world 1
-  c3  Llama-3.2-1B CLT     d=2048, k=64,  M=16384, L=3, cross 3, skip + post_encoder_scale          world 2 and 4
-  c4  Llama-3-8B SAE       d=4096, k=192, M=32768 (shards of 16384 = 131072 / 8), unit-norm decoder  world 2
+  c3  Llama-3.2-1B CLT     d=2048, k=64,  M=16384, L=3, cross 3, skip + post_encoder_scale          world 2, 4 and 8
+  c4  Llama-3-8B SAE       d=4096, k=192, M=32768 (shards of 16384 = 131072 / 8), unit-norm decoder  world 2 and 4
+  c5  GPT-2 per-target tied d=768,  k=32,  M=12288, L=3, coalesce_topk="concat" + post_encoder_scale  world 1 and 2
+      (BASELINE configs[4]: the path ``bench.py --coalesce concat`` times; runner.py:93-127)
 
 N = 512 tokens per step, bf16 parameters and activations, fused Adam (row passes), one-launch fan-out, 3 steps.
 world > 1: one process per rank, all on the one GPU, collectives staged through gloo (RCCL needs a GPU per rank);
@@ -16,8 +18,11 @@ What is compared (tolerances of BASELINE.json: rtol 1e-2 in bf16, index sets exa
   * the oracle is evaluated on the engine's selection (forced_idx): top activations, reconstruction, FVU at 1e-2;
   * gradients THROUGH the fused path: the schedule's first step has lr = 0 (LambdaLR, trainer.py:45-58, 797-802), so
     after it exp_avg = (1 - b1) * grad exactly -- compared with the oracle's closed-form gradient at 2e-2 (norm-wise);
-  * every parameter after 3 steps at 1e-2 (norm-wise), and the parameter UPDATE (p_3 - p_0) at 0.15: Adam's
-    element-wise g / sqrt(v) amplifies bf16 gradient noise on near-zero elements, the bound is ours.
+  * every parameter after 3 steps at 1e-2 (norm-wise), and the parameter UPDATE (p_3 - p_0) ELEMENT-WISE wherever the
+    gradient is well above its noise (|g| > 1e-3 max|g| at the first step): within 15 % of the oracle's update plus
+    1.5 bf16 spacings of the parameter (the engine rounds a bf16 parameter after every step, the fp32 oracle does not),
+    on all but 2 % of those elements (0.8 % measured at worst); norm-wise at 0.15 on the rest, where Adam's g / sqrt(v) amplifies bf16 gradient
+    noise.  (Adam's update does not see a constant factor on a gradient: scale errors are the exp_avg check's job.)
 """
 import os
 import sys
@@ -39,6 +44,8 @@ SHAPES = {
     "c3_llama1b_clt": dict(d=2048, k=64, M=16384, L=3, cross=3,
                            sae=dict(transcode=True, skip_connection=True, post_encoder_scale=True)),
     "c4_llama8b_sae": dict(d=4096, k=192, M=32768, L=1, cross=0, sae=dict(transcode=False, normalize_decoder=True)),
+    "c5_gpt2_concat": dict(d=768, k=32, M=12288, L=3, cross=3,
+                           sae=dict(transcode=True, skip_connection=True, post_encoder_scale=True, coalesce_topk="concat")),
 }
 N_TOK, STEPS, LR, WARMUP, B1 = 512, 3, 2e-3, 2, 0.9
 
@@ -131,6 +138,7 @@ def _worker(rank, world, port, shape, out_dir):
             rec["after0"] = {f"{l}.{n}": p.detach().float().cpu() for l, c in enumerate(coders)
                              for n, p in c.named_parameters()}
     rec["state"] = {f"{l}.{n}": p.detach().float().cpu() for l, c in enumerate(coders) for n, p in c.named_parameters()}
+    rec["bf16"] = [f"{l}.{n}" for l, c in enumerate(coders) for n, p in c.named_parameters() if p.dtype == torch.bfloat16]
     torch.save(rec, f"{out_dir}/rank{rank}.pt")
     dist.destroy_process_group()
 
@@ -146,6 +154,7 @@ def oracle_tensors(lp):
         t[f"b_decs.{i}"] = lp.b_decs[i]
         if lp.W_skips[i] is not None:
             t[f"W_skips.{i}"] = lp.W_skips[i]
+    for i in range(len(lp.post_encs)):  # (concat: one decoder per layer, but one post-encoder vector per target)
         t[f"post_encs.{i}"] = lp.post_encs[i]
         if lp.post_enc_scales is not None:
             t[f"post_enc_scales.{i}"] = lp.post_enc_scales[i]
@@ -187,7 +196,8 @@ def run_shape(shape, world, tmp_path):
         for r in range(1, world):  # the merge is replicated knowledge: every rank ends with the same [N, k]
             for l in range(L):
                 assert torch.equal(res[r]["idx"][s][l], forced[l]), (s, l, r)
-        r_ = O.clt_train_step(layers, xs, ys, m, k, act_dtype=torch.bfloat16, forced_idx=forced)
+        r_ = O.clt_train_step(layers, xs, ys, m, k, act_dtype=torch.bfloat16, forced_idx=forced,
+                              coalesce=sae_kw.get("coalesce_topk", "none"))
         for l, lp in enumerate(layers):
             idx = forced[l]
             assert idx.shape == (N_TOK, k) and int(idx.min()) >= 0 and int(idx.max()) < M
@@ -205,6 +215,7 @@ def run_shape(shape, world, tmp_path):
             for l, lp in enumerate(layers):
                 r_.grads[l]["W_decs.0"] = O.remove_parallel_grad(lp.W_decs[0].double(), r_.grads[l]["W_decs.0"])
         if s == 0:
+            g0 = [{n: g.clone() for n, g in r_.grads[l].items()} for l in range(L)]
             seen = 0
             for l in range(L):
                 for n, g in r_.grads[l].items():
@@ -242,11 +253,23 @@ def run_shape(shape, world, tmp_path):
                     continue  # re-normalised every step on both sides: compared through fvu / reconstruction above
                 assert rel(got, want) < 1e-2, (l, n, r, rel(got, want))
                 if float((want - init).norm()) > 0:
-                    e = rel(got - init, want - init)
-                    assert e < 0.15, (l, n, r, e)
+                    g = g0[l][n][r * Ml:(r + 1) * Ml] if sharded else g0[l][n]
+                    clear = g.abs() > 1e-3 * g0[l][n].abs().max()  # the gradient is well above its bf16 noise here
+                    du, dw = (got - init).double(), (want - init).double()
+                    spacing = init.abs().double() * 2.0**-7 if f"{l}.{n}" in res[r]["bf16"] else 0.0
+                    bad = ((du - dw).abs() > 0.15 * dw.abs() + 1.5 * spacing + 1e-9) & clear
+                    n_clear = int(clear.sum())
+                    # measured: at most 0.8 % of the clear elements miss the bound (the fp32 skip matrices, whose gradient
+                    # is a bf16 GEMM over all tokens), 0.4 % everywhere else; a missing contribution or a wrong sign moves
+                    # tens of per cent of them
+                    assert n_clear == 0 or int(bad.sum()) <= 2e-2 * n_clear, (l, n, r, int(bad.sum()), n_clear)
+                    if int((~clear).sum()) > 0 and float(dw[~clear].norm()) > 0:
+                        e = float((du[~clear] - dw[~clear]).norm() / dw[~clear].norm())
+                        assert e < 0.15, (l, n, r, e)
 
 
 @pytest.mark.parametrize("shape,world", [("c2_gpt2_clt", 1), ("c3_llama1b_clt", 2), ("c3_llama1b_clt", 4),
-                                         ("c4_llama8b_sae", 2)])
+                                         ("c3_llama1b_clt", 8), ("c4_llama8b_sae", 2), ("c4_llama8b_sae", 4),
+                                         ("c5_gpt2_concat", 1), ("c5_gpt2_concat", 2)])
 def test_engine_bf16_at_config_widths_vs_oracle(shape, world, tmp_path):
     run_shape(shape, world, tmp_path)
