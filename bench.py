@@ -57,26 +57,26 @@ class SimComm:
     def __init__(self, world, m_local):
         self.enabled, self.group, self.world, self.rank, self.backend, self.m_local = True, None, world, 0, "sim", m_local
 
-    def all_gather_rows(self, t):
+    def all_gather_rows(self, t, tag=None):
         return torch.cat([t.roll(37 * r, 0) for r in range(self.world)], 0)
 
-    def all_gather_cat1(self, t):
+    def all_gather_cat1(self, t, tag=None):
         parts = [t.roll(37 * r, 0) for r in range(self.world)]
         if t.dtype == torch.int64:  # global candidate indices: pretend rank r owns [r * m_local, (r + 1) * m_local)
             parts = [p + r * self.m_local for r, p in enumerate(parts)]
         return torch.cat(parts, 1).contiguous()
 
-    def all_to_all_rows(self, t):
+    def all_to_all_rows(self, t, tag=None):
         n = t.shape[0] // self.world
         parts = [t[:n].roll(37 * r, 0) for r in range(self.world)]
         if t.dtype == torch.int64:  # packed (value bits << 32 | global index) candidates of pretend rank r
             parts = [p + r * self.m_local for r, p in enumerate(parts)]
         return torch.cat(parts, 0)
 
-    def reduce_scatter_rows(self, t):
+    def reduce_scatter_rows(self, t, tag=None):
         return t[: t.shape[0] // self.world].clone()
 
-    def all_reduce_(self, t):
+    def all_reduce_(self, t, tag=None):
         return t
 
 
@@ -249,6 +249,8 @@ def main():
         sim = SimComm(args.simulate_tp, M // args.simulate_tp) if args.simulate_tp > 1 and world == 1 else None
         trainer = TPTrainer(cfg, batches, device=device, num_batches=10_000, comm=sim)
         parallelism = f"tp{world}" if world > 1 else "single"
+        if world > 1 and os.environ.get("CLT_BENCH_REHEARSAL"):
+            parallelism = f"REHEARSAL of tp{world}: every rank on GPU 0, gloo on host copies, no RCCL"
         if sim is not None:
             world, parallelism = args.simulate_tp, f"SIMULATED rank 0 of tp{args.simulate_tp}, no RCCL"
     else:
@@ -285,9 +287,15 @@ def main():
     t0 = time.perf_counter()
     stride = max(1, args.event_stride)
     sampled = len(range(0, args.steps, stride))
+    comm = getattr(trainer, "comm", None)
+    coll = {} if real_world > 1 and hasattr(comm, "timing") else None  # collectives: events on the sampled steps only
     for i in range(args.steps):
         prof.active = i % stride == 0
+        if coll is not None:
+            comm.timing = coll if prof.active else None
         fv = trainer.step(batches[i % len(batches)])
+    if coll is not None:
+        comm.timing = None
     t_enqueue = time.perf_counter() - t0  # host time to issue the steps: close to dt means launch-bound
     barrier()
     dt = time.perf_counter() - t0
@@ -367,7 +375,11 @@ def main():
             cpu["c1"] = cpu_baseline.run_c1(min_seconds=6.0)  # BASELINE configs[0], whole steps, not extrapolated
         line = {
             "metric": "train tokens/sec, GPT-2 CLT (exp128,k32) fwd+bwd+Adam", "value": round(value, 1),
-            "unit": "tokens/s", "n_gpus": real_world, "simulated": args.simulate_tp > 1 and real_world == 1, "steps": args.steps, "warmup": args.warmup,
+            "unit": "tokens/s", "n_gpus": real_world,
+            # simulated: not a measurement of the metric -- one GPU doing rank 0's compute (--simulate-tp), or several
+            # ranks sharing GPU 0 over gloo (CLT_BENCH_REHEARSAL)
+            "simulated": (args.simulate_tp > 1 and real_world == 1) or (real_world > 1 and bool(os.environ.get("CLT_BENCH_REHEARSAL"))),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             # wall time the host spent enqueueing the timed steps.  It INCLUDES back-pressure: the HIP queue is bounded, so
             # once the host is a few hundred launches ahead of a GPU-bound step its launch calls block.  The pure host
@@ -385,6 +397,17 @@ def main():
                              f"{stride}{'st' if stride == 1 else 'th'}), on the launch stream",
             "kernels": kernels, "cpu_baseline": cpu,
         }
+        if real_world > 1:
+            # what the scaling number is made of (the method of scripts/benchmarks/distributed.py:11-57, per collective):
+            # each class of exchange timed with HIP events on the stream that issued it, rank 0, sampled steps; with
+            # overlap on, the encoder half's collectives (input all-gather, candidate exchange) run on the side stream
+            # beside the decoder / backward kernels of the previous layer, so their time is not additive to the step
+            from clt_training_amd.engine import ROUTES as _R
+
+            line["rccl"] = {"world": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend()}
+            line["collectives"] = comm.timing_summary(sampled, coll) if coll is not None else None
+            line["collectives_timing"] = "HIP events around every collective on the issuing stream, rank 0, sampled steps"
+            line["overlap"] = {"two_streams": bool(_R.overlap), "encoder_half_on_side_stream": bool(_R.overlap)}
         print(json.dumps(line), flush=True)
     if real_world > 1:
         torch.distributed.destroy_process_group()

@@ -91,44 +91,77 @@ class Comm:
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.backend = dist.get_backend(group) if self.enabled else "none"
+        # bench.py: HIP events around every collective, recorded on the stream that issues it (the stream whose work
+        # waits for the result), summed per class of exchange -- the method of scripts/benchmarks/distributed.py:11-57
+        # applied per collective.  Off (None) outside the benchmark: an event pair costs ~10 us of idle GPU.
+        self.timing: Optional[dict] = None
+
+    def _timed(self, tag: str, t: Tensor, fn):
+        if self.timing is None or not t.is_cuda:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.timing.setdefault(tag, []).append((s, e, t.numel() * t.element_size()))
+        return out
+
+    def timing_summary(self, steps: int, timing: Optional[dict] = None) -> dict:
+        """{class: {calls_per_step, ms_per_step, bytes_per_call}} of the collectives recorded in ``timing`` (default:
+        the dict currently attached) over ``steps`` steps; call after a device synchronise."""
+        out = {}
+        for tag, evs in (timing if timing is not None else self.timing or {}).items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in evs)
+            out[tag] = {"calls_per_step": round(len(evs) / steps, 2), "ms_per_step": round(ms / steps, 4),
+                        "bytes_per_call": int(sum(b for _, _, b in evs) / max(1, len(evs)))}
+        return out
 
     # gloo (CPU tests, and rehearsals of the multi-rank GPU path on a one-GPU box) works on host copies
-    def all_gather_rows(self, t: Tensor) -> Tensor:
+    def all_gather_rows(self, t: Tensor, tag: str = "all_gather") -> Tensor:
         """[n, ...] per rank -> [world * n, ...] (rank-major)."""
         if self.world == 1:
             return t
         t = t.contiguous()
+        return self._timed(tag, t, lambda: self._all_gather_rows(t))
+
+    def _all_gather_rows(self, t: Tensor) -> Tensor:
         if self.backend == "gloo" and t.is_cuda:
-            return self.all_gather_rows(t.cpu()).to(t.device)
+            return self._all_gather_rows(t.cpu()).to(t.device)
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t, group=self.group)
         return out
 
-    def all_gather_cat1(self, t: Tensor) -> Tensor:
+    def all_gather_cat1(self, t: Tensor, tag: str = "all_gather") -> Tensor:
         """[N, k] per rank -> [N, world * k] (candidates of every shard side by side)."""
         if self.world == 1:
             return t
-        g = self.all_gather_rows(t)  # [world * N, k]
+        g = self.all_gather_rows(t, tag)  # [world * N, k]
         N, k = t.shape
         return g.view(self.world, N, k).permute(1, 0, 2).reshape(N, self.world * k).contiguous()
 
-    def all_to_all_rows(self, t: Tensor) -> Tensor:
+    def all_to_all_rows(self, t: Tensor, tag: str = "all_to_all") -> Tensor:
         """[world * n, ...] per rank (block r' = what this rank sends to rank r') -> [world * n, ...] whose block r'
         is what rank r' sent here."""
         if self.world == 1:
             return t
         t = t.contiguous()
+        return self._timed(tag, t, lambda: self._all_to_all_rows(t))
+
+    def _all_to_all_rows(self, t: Tensor) -> Tensor:
         if self.backend == "gloo" and t.is_cuda:
-            return self.all_to_all_rows(t.cpu()).to(t.device)
+            return self._all_to_all_rows(t.cpu()).to(t.device)
         out = torch.empty_like(t)
         dist.all_to_all_single(out, t, group=self.group)
         return out
 
-    def reduce_scatter_rows(self, t: Tensor) -> Tensor:
+    def reduce_scatter_rows(self, t: Tensor, tag: str = "reduce_scatter") -> Tensor:
         """sum over ranks of [world * n, d], rank r keeps rows [r*n, (r+1)*n)."""
         if self.world == 1:
             return t
         t = t.contiguous()
+        return self._timed(tag, t, lambda: self._reduce_scatter_rows(t))
+
+    def _reduce_scatter_rows(self, t: Tensor) -> Tensor:
         n = t.shape[0] // self.world
         if self.backend == "gloo":  # gloo has no reduce_scatter: all-reduce and slice
             h = t.cpu() if t.is_cuda else t
@@ -140,15 +173,18 @@ class Comm:
         dist.reduce_scatter_tensor(out, t, group=self.group)
         return out
 
-    def all_reduce_(self, t: Tensor) -> Tensor:
+    def all_reduce_(self, t: Tensor, tag: str = "all_reduce") -> Tensor:
         if self.world > 1:
-            if self.backend == "gloo" and t.is_cuda:
-                h = t.cpu()
-                dist.all_reduce(h, group=self.group)
-                t.copy_(h)
-            else:
-                dist.all_reduce(t, group=self.group)
+            self._timed(tag, t, lambda: self._all_reduce_(t))
         return t
+
+    def _all_reduce_(self, t: Tensor) -> None:
+        if self.backend == "gloo" and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
 
 
 # --------------------------------------------------------------------------- sharded parameters
@@ -433,20 +469,20 @@ class CLTEngine:
         assert N % tp == 0
         vdt = v.dtype
         if hasattr(ops, "candidates_pack"):  # two small kernels either side of each collective (clt_candidates_*)
-            mine = comm.all_to_all_rows(ops.candidates_pack(v, idx, lat_begin))  # [tp * N/tp, k]: block r' from rank r'
+            mine = comm.all_to_all_rows(ops.candidates_pack(v, idx, lat_begin), "candidate_all_to_all")  # [tp * N/tp, k]: block r' from rank r'
             cand_v, cand_i = ops.candidates_unpack(mine, tp, k, vdt)         # [N/tp, tp * k], rank by rank
             mv, mi = ops.topk_rows(cand_v, k, cand_idx=cand_i)
-            win = comm.all_gather_rows(ops.candidates_pack(mv, mi))          # [N, k]
+            win = comm.all_gather_rows(ops.candidates_pack(mv, mi), "candidate_all_gather")          # [N, k]
             return ops.candidates_unpack(win, 1, k, vdt)
         # (the oracle-backed ops double of the CPU tests: the same format in torch ops)
         packed = (v.float().view(torch.int32).to(torch.int64) << 32) | (idx + lat_begin)  # post-ReLU: sign bit clear
-        mine = comm.all_to_all_rows(packed)
+        mine = comm.all_to_all_rows(packed, "candidate_all_to_all")
         n = N // tp
         cand = mine.view(tp, n, k).permute(1, 0, 2).reshape(n, tp * k)
         cand_v = (cand >> 32).to(torch.int32).view(torch.float32).to(vdt)
         cand_i = cand & 0xFFFFFFFF
         mv, mi = ops.topk_rows(cand_v.contiguous(), k, cand_idx=cand_i.contiguous())
-        win = comm.all_gather_rows((mv.float().view(torch.int32).to(torch.int64) << 32) | mi)  # [N, k]
+        win = comm.all_gather_rows((mv.float().view(torch.int32).to(torch.int64) << 32) | mi, "candidate_all_gather")  # [N, k]
         return (win >> 32).to(torch.int32).view(torch.float32).to(vdt), win & 0xFFFFFFFF
 
     @torch.no_grad()
@@ -499,7 +535,7 @@ class CLTEngine:
             x_r = y_r
         xn_r = x_r.float() * (d**0.5 / lp.in_norm) if cfg.normalize_io else x_r
         x_enc_r = xn_r if cfg.transcode else xn_r.float() - lp.b_decs[0]
-        x_enc = comm.all_gather_rows(x_enc_r.to(cd))
+        x_enc = comm.all_gather_rows(x_enc_r.to(cd), "input_all_gather")
         fired = None
         if cfg.activation == "groupmax":
             # fused_encoder.py:373-413: the k groups are runs of consecutive latents, so each shard owns k / tp whole
@@ -508,7 +544,7 @@ class CLTEngine:
             v, idx = ops.encode_topk(x_enc, lp.W_enc, lp.b_enc, k // comm.world, out_dtype=cd, activation="groupmax")
             if comm.world > 1:
                 packed = (v.float().view(torch.int32).to(torch.int64) << 32) | (idx + lp.lat_begin)
-                win = comm.all_gather_cat1(packed)
+                win = comm.all_gather_cat1(packed, "candidate_all_gather")
                 v, idx = (win >> 32).to(torch.int32).view(torch.float32).to(cd), win & 0xFFFFFFFF
         else:
             if cfg.activation not in ("topk", "batchtopk"):
@@ -622,22 +658,22 @@ class CLTEngine:
                         li = self.coders[st.layer]
                         if li.W_skips is not None:
                             E = E + (st.xn_r @ li.W_skips[st.slot].to(cd).mT).float() * sc_  # sparse_coder.py:190
-            yhat_r = comm.reduce_scatter_rows(P).float() + E
+            yhat_r = comm.reduce_scatter_rows(P, "output_reduce_scatter").float() + E
             if denorm is not None:
                 yhat_r = yhat_r * denorm
         if self.keep_outputs:
             self.last_out[j] = yhat_r
 
         # ---------------- FVU on token shards (sparse_coder.py:207-221)
-        colsum = comm.all_reduce_(ops.fvu_colsum(y_r, mask_r))
-        l2tv = comm.all_reduce_(ops.fvu_partial(y_r, yhat_r, mask_r, colsum))
+        colsum = comm.all_reduce_(ops.fvu_colsum(y_r, mask_r), "fvu_all_reduce")
+        l2tv = comm.all_reduce_(ops.fvu_partial(y_r, yhat_r, mask_r, colsum), "fvu_all_reduce")
         sc, G_r = ops.fvu_grad(y_r, yhat_r, mask_r, l2tv, gscale=1.0 / acc_steps, g_dtype=cd)
         fvu = sc[0]
 
         # ---------------- backward
         if denorm is not None:
             G_r = (G_r.float() * denorm).to(cd)
-        G = comm.all_gather_rows(G_r)
+        G = comm.all_gather_rows(G_r, "loss_gradient_all_gather")
         G_div = G if div == 1 else (G.float() / div).to(cd)
         G_r_div = G_r if div == 1 else (G_r.float() / div).to(cd)
         gb = G_r.sum(0, dtype=torch.float32)  # d b_dec: the same column sums for every live source (x 1/div)
@@ -769,17 +805,17 @@ class CLTEngine:
             yhat_r, acts_l = ops.decode_fwd_multi(srcs, bias=bias, out=S, accumulate=True, round_acts=rb, want_acts=True)
         else:
             P, acts_l = ops.decode_fwd_multi(srcs, round_acts=rb, want_acts=True)
-            yhat_r = comm.reduce_scatter_rows(P).float() + (bias if S is None else S + bias)
+            yhat_r = comm.reduce_scatter_rows(P, "output_reduce_scatter").float() + (bias if S is None else S + bias)
             if denorm is not None:
                 yhat_r = yhat_r * denorm
         if self.keep_outputs:
             self.last_out[j] = yhat_r
-        colsum = comm.all_reduce_(ops.fvu_colsum(y_r, mask_r))
-        l2tv = comm.all_reduce_(ops.fvu_partial(y_r, yhat_r, mask_r, colsum))
+        colsum = comm.all_reduce_(ops.fvu_colsum(y_r, mask_r), "fvu_all_reduce")
+        l2tv = comm.all_reduce_(ops.fvu_partial(y_r, yhat_r, mask_r, colsum), "fvu_all_reduce")
         sc, G_r = ops.fvu_grad(y_r, yhat_r, mask_r, l2tv, gscale=1.0 / acc_steps, g_dtype=cd)
         if denorm is not None:
             G_r = (G_r.float() * denorm).to(cd)
-        G = comm.all_gather_rows(G_r)
+        G = comm.all_gather_rows(G_r, "loss_gradient_all_gather")
         self._acc_grad(lp.b_decs[0], G_r.sum(0, dtype=torch.float32))
         if lp.W_skips is not None:
             self._acc_grad(lp.W_skips[0], _mm_f32(G_r.mT, me.xn_r))
@@ -918,7 +954,7 @@ class CLTEngine:
         if not grads:
             return
         flat = torch.cat([g.reshape(-1).float() for g in grads])
-        self.comm.all_reduce_(flat)
+        self.comm.all_reduce_(flat, "replicated_grads_all_reduce")
         off = 0
         for g in grads:
             n = g.numel()
