@@ -463,6 +463,9 @@ def main(only=None):
             golden_trainer("trainer_clt_kl", dict(clt, post_encoder_scale=True), cross=3, b1=0.9, seed=32, loss_fn="kl")
         # loss_fn="kl-fvu" cannot be driven with mesh=None: trainer.py:764-769 wraps kl in DTensor.from_local(kl, self.mesh,
         # ...) unconditionally and torch raises "No device mesh is currently active!" (tried here) -- no golden for it.
+        # Round 3 tried a world-1 CPU mesh (tests/golden/attempt_klfvu_mesh.py): AssertionError at sparse_coder.py:276
+        # (dtensor.rand on a CPU mesh) with the mesh in the constructor, "mixed torch.Tensor and DTensor" at
+        # trainer.py:565 with the mesh attached afterwards.  Still no golden: kl-fvu stays parity unpinned.
         golden_trainer("trainer_sae_kl", dict(expansion_factor=8, k=4, transcode=False), cross=0, b1=0.9, seed=34,
                        loss_fn="kl")
         return
