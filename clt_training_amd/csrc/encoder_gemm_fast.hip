@@ -40,7 +40,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast_kernel(const FastArgs p
   const char* __restrict__ xb = p.x;
   const char* __restrict__ Wb = p.W;
   const char* __restrict__ bias = p.bias;
-  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt, dbg = p.dbg;
+  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt;
+#ifdef CLT_TUNING  // timing ablations (tools/): 1 = no stores, 2 = no filter scan, 4 = no LDS-DMA, 8 = no MFMAs
+  const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
   const int* __restrict__ tt_map = p.tt_map;
   const int64_t N = p.N, M = p.M;
   const int lane = threadIdx.x & 63;

@@ -71,12 +71,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Fragment read from inline asm: as plain loads hipcc sank all 16 reads of a k-step below its last MFMA (nothing pins a
 // load between sched_barriers), which exposed the LDS latency once per step.  Volatile asm keeps its place; the wait
 // for the results is ours (frag_wait).
-// Instruction slots of a k-step (slot t = after MFMA t), per wave.  The four waves leave the step's barrier together
-// and run at the same pace, so with ONE slot table they would hand their LDS-DMAs to the CU's single address path in
-// the same cycles and queue behind each other (measured: the DMAs cost 201 us of a 906 us filter pass that way, 28 %).
-// Wave w therefore issues its q-th DMA of the step after MFMA 2 + 7 q + {0, 2, 4, 5}[w]: the CU sees one DMA every
-// 1-2 MFMAs instead of four at once every seventh.  Each wave runs its own copy of the k-step (a switch on the wave
-// number around the step pair; ~1 KB of code per copy).
+// Instruction slots of a k-step (slot t = after MFMA t): one table for all four waves (w = 0): the q-th DMA of the step
+// after MFMA 2 + 7 q, the p-th fragment read after MFMA 3 + 3 p (or the next slot when that one holds a DMA).  A
+// per-wave skew of the DMA slots (w > 0 below: each wave its own copy of the k-step behind a switch on the wave number)
+// was built to keep the four waves from handing their LDS-DMAs to the CU's address path in the same cycles; hipcc
+// spilled 744 registers over the four copies and the skew was dropped -- the kernel instantiates w = 0
+// only.
 __host__ __device__ constexpr int dma_q_at(int w, int t) {  // the real DMA (0..3 W pieces, 4..7 x pieces, 8 aux) or -1
   const int sh = w == 0 ? 0 : w == 1 ? 2 : w == 2 ? 4 : 5;
   const int r = t - 2 - sh;
@@ -141,7 +141,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_fast16_kernel(const FastArgs
   const char* __restrict__ xb = p.x;
   const char* __restrict__ Wb = p.W;
   const char* __restrict__ bias = p.bias;
-  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt, dbg = p.dbg;
+  const int bias_esize = p.bias_esize, kbytes = p.kbytes, nlt = p.nlt;
+#ifdef CLT_TUNING  // timing ablations (tools/): 1 = no stores
+  const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
   const int* __restrict__ tt_map = p.tt_map;
   const int64_t N = p.N;
   const int ngroups = p.ngroups;  // valid virtual groups of 16 latent rows (host: launch_gemm_fast)

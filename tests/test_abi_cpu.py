@@ -113,3 +113,28 @@ def test_trainer_construction_rule():
     assert lr == 0.0  # LambdaLR applies factor(0) = 0 at construction: first step runs with lr 0
     sch = tr.lr_schedulers[0]
     assert sch.lr_lambda(1) == 0.5 and sch.lr_lambda(2) == 1.0 and sch.lr_lambda(6) == 0.5
+
+
+def test_encoder_gemm_kernels_use_no_scratch():
+    """The persistent encoder GEMM kernels run at the edge of their register budget (256 VGPRs at two waves per SIMD,
+    512 at one).  A spilled register is more than a slow access there: its reload is a vector-memory load, so hipcc puts
+    ``s_waitcnt vmcnt(0)`` in front of it and the kernel's LDS-DMA prefetch ring drains once per tile (seen in round 3
+    with two registers of the eight-wave kernel).  hipcc's own resource report must show no scratch for them."""
+    import re
+    import subprocess
+
+    from clt_training_amd.build import CSRC, FLAGS, HIPCC
+
+    for src, kernels in (("encoder_gemm_w8.hip", ("gemm_w8_filter_kernel",)), ("encoder_gemm_fast16.hip", ("gemm_fast16_kernel",))):
+        out = subprocess.run([HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(CSRC / src), "-o", "/dev/null"],
+                             capture_output=True, text=True, check=True).stderr
+        blocks = re.split(r"remark: Function Name: ", out)[1:]
+        seen = 0
+        for b in blocks:
+            name = b.split()[0]
+            if any(k in name for k in kernels):
+                seen += 1
+                scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+                spills = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+                assert scratch == 0 and spills == 0, (src, name, scratch, spills)
+        assert seen >= 1, (src, "kernel not found in the resource report")
