@@ -476,10 +476,13 @@ __global__ __launch_bounds__(NT8) void gemm_w8_filter_kernel(const FastArgs p) {
           }
           CLT_FENCE();
         }
+        // The queue is written out whenever it holds a full row of 64 entries (dense 1 KiB stores) at the end of a latent
+        // row: a latent row (4 groups x 64 lanes) can then always add 97 entries -- 50 times its mean at the BASELINE
+        // shapes, 8 times that of a tp8 shard (where ~95 entries per tile and wave overflowed a queue that was only
+        // emptied at tile ends: 26 of 256 token tiles fell back at N = 65536, M = 12288).  (Cadences of 1, 4 and 8
+        // tiles, all waves together, were measured at C2: no difference.)
+        if (qn >= 64) flush_queue();
       }
-      // The queue is written out once it holds a full row of 64 entries (dense 1 KiB stores), so a tile can always add
-      // QCAP8 - 127 = 97 entries and usually 161 -- ten times the mean at the BASELINE shapes, twice that of a tp8 shard.
-if (qn >= 64) flush_queue();  // (cadences of 1, 4 and 8 tiles, all waves together, were measured: no difference)
       if (q_over && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
         atomicOr(p.fb_flags + 1 + cur_tt, 1);
       ks = 0;

@@ -591,6 +591,8 @@ def test_fused_encode_topk_fallback_is_per_token_tile(ops):
 @pytest.mark.parametrize("N,M,d,k", [(2048, 12288, 768, 32),    # C2 at tp8: the shard of 98304 latents
                                      (1024, 16384, 2048, 64),   # configs[2] (Llama-3.2-1B CLT) at tp8
                                      (2048, 98304, 768, 32),    # C2 unsharded
+                                     (16384, 12288, 768, 32),   # the tp8 shard on the gathered batch of 8 ranks: ~95
+                                                                # queue entries per wave and tile (flush at row ends)
                                      (512, 131072, 256, 192)])  # configs[3]'s latents and k (d cut to 256): ~500 candidates
                                                                 # per token in > 256 non-empty list groups for the merge
 def test_fused_encode_topk_stays_on_the_fused_path(ops, N, M, d, k):
