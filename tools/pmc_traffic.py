@@ -27,7 +27,10 @@ RULES = [
     ("decode_fwd_kernel", "", "clt_decode_fwd"),
     ("decode_bwd_acts_kernel", "", "clt_decode_bwd_acts"),
     ("spt_dense_kernel", "", "spt_dense_kernel (register variant)"),
+    ("fused_select_stream_kernel", "", "fused_select_stream_kernel"),
     ("fused_select_kernel", "", "fused_select_kernel"),
+    ("fused_bucket_kernel", "", "fused_bucket_kernel"),
+    ("gemm_w8_filter_kernel", "", "gemm_w8_filter_kernel"),
     ("topk_rows_kernel", "", "clt_topk_rows(sample)"),
     ("adam_kernel", "", "clt_adam_step"),
     ("pack_x_kernel", "", "pack_x_kernel"),
@@ -72,9 +75,11 @@ def main():
         if tag in JOBS:  # batched launch: the probe's launches hold JOBS[tag] (source, target) pairs each
             kernels[tag]["jobs_per_launch"] = JOBS[tag]
             kernels[tag]["hbm_bytes_per_job"] = kernels[tag]["hbm_bytes"] // JOBS[tag]
-    # the fused encoder call = sample GEMM + sample top-k + filter GEMM + merge (its gated fallback launches fetch nothing)
-    stages = [k for k in kernels if k.startswith("gemm_fast_kernel") or k in ("clt_topk_rows(sample)", "fused_select_kernel",
-                                                                          "pack_x_kernel")]
+    # the fused encoder call = x pack + sample GEMM + sample top-k + filter GEMM + bucket + merge (its gated fallback
+    # launches fetch nothing)
+    stages = [k for k in kernels if k.startswith("gemm_fast_kernel") or k in (
+        "clt_topk_rows(sample)", "fused_select_kernel", "fused_select_stream_kernel", "fused_bucket_kernel",
+        "gemm_w8_filter_kernel", "pack_x_kernel")]
     if stages:
         kernels["clt_encode_topk_fwd"] = {"stages": stages, "hbm_bytes": sum(kernels[k]["hbm_bytes"] for k in stages)}
     doc = {"command": "rocprofv3 --pmc FETCH_SIZE (then, in a second run, --pmc WRITE_SIZE) --output-format csv -- python3 "
