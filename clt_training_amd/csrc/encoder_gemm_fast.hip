@@ -434,6 +434,114 @@ __global__ void tau_kernel(const uint16_t* __restrict__ svals, int k, int m, int
   tau[t] = v;
 }
 
+// Row top-k of the SAMPLE matrix (pass A) + the token's threshold in one launch, for rows that fit the registers of a
+// wave (bf16, k <= 32, at most 512 NCH <= 6144 columns): the results are clt_topk_rows' bit for bit (same keys, same
+// WaveSelect), what differs is how few elements reach the selection.  The generic kernel streams a row chunk by chunk and
+// learns its threshold on the way (~k ln(L / k) survivors, five or six queue merges per row, each chunk's load waited
+// for in turn); here every load of the row is in flight at once, a packed integer max per lane (post-ReLU bf16: the
+// signed 16-bit order is the value order, negative patterns stay below every candidate) gives 128 sub-maxima -- 128
+// DISTINCT elements of the row -- whose k-th largest (a 16-step bit search over two ballots) is a lower bound of the
+// row's k-th largest value, and only the elements at or above it (~40 at L = 6144, k = 32) are offered.  One merge
+// per row.  HBM-bound: L * 2 bytes per row, read once (the sample matrix is still in the Infinity Cache).
+// tau[t] = lower edge of the bf16 rounding interval of the sample's m-th value (tau_kernel's rule), +inf for the padding
+// rows of the last token tile.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+template <int NCH>
+__global__ __launch_bounds__(256) void sample_topk_kernel(const uint16_t* __restrict__ pre, int64_t ld, int64_t N,
+                                                          int64_t Npad, int L, int k, int m,
+                                                          uint16_t* __restrict__ svals, int64_t* __restrict__ sidx,
+                                                          float* __restrict__ tau) {
+  __shared__ u64 lds_q[4][192];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= Npad) return;
+  if (row >= N) {
+    if (lane == 0) tau[row] = __builtin_inff();
+    return;
+  }
+  const uint16_t* rp = pre + row * ld;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 c[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int e0 = (j * 64 + lane) * 8;  // (L is a multiple of 16: a chunk is inside the row or outside)
+    c[j] = e0 < L ? *reinterpret_cast<const u32x4*>(rp + e0) : zero4;
+  }
+  i16x2 mx = {0, 0};
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(i16x2, c[j][w]));
+  const int lo = mx.x, hi = mx.y;  // >= 0
+  const int kk = k < 128 ? k : 128;
+  int T0 = 0;  // largest t with at least kk sub-maxima >= t (0: fewer than kk positive ones, every positive value is offered)
+#pragma unroll
+  for (int b = 14; b >= 0; --b) {
+    const int t = T0 | (1 << b);
+    const int cnt = __popcll(__ballot(lo >= t)) + __popcll(__ballot(hi >= t));
+    if (cnt >= kk) T0 = t;
+  }
+  const int T1 = T0 > 1 ? T0 : 1;  // candidates are positive
+  WaveSelect<1, 4, true> ws;
+  ws.init(lds_q[wave], lane, k);
+  ws.set_bits(48, 32 - __clz(L > 1 ? L - 1 : 1));
+  // survivors -> the wave's LDS queue, densely (straight-line code: the row stays in registers); a row with more than
+  // the queue takes (heavy ties at the bound) is redone below the generic way
+  int cnt = 0;
+  bool over = false, sorted = false;
+  const i16x2 T1pk = {(short)T1, (short)T1};
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t word = c[j][w];
+      const i16x2 pr = __builtin_bit_cast(i16x2, word);
+      // either half at the bound?  One packed saturating subtract: the sign bits of (half - T1) are clear where it is
+      if (__ballot((~__builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(pr, T1pk)) & 0x80008000u) != 0u) == 0ull) continue;
+      const bool c0 = pr.x >= T1, c1 = pr.y >= T1;
+      const u64 b0 = __ballot(c0), b1 = __ballot(c1);
+      if (!over) {  // (wave-uniform)
+        if (cnt + __popcll(b0) + __popcll(b1) > 192) {
+          over = true;
+        } else {
+          const unsigned col = (unsigned)((j * 64 + lane) * 8 + w * 2);
+          const int p0 = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0));
+          if (c0) ws.q[p0] = ((u64)(word << 16) << 32) | (u64)(~col);
+          cnt += __popcll(b0);
+          const int p1 = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0));
+          if (c1) ws.q[p1] = ((u64)(word & 0xffff0000u) << 32) | (u64)(~(col + 1u));
+          cnt += __popcll(b1);
+        }
+      }
+    }
+  if (!over && cnt <= 64) {  // the usual case: one key per lane, one 64-key bitonic sort, done
+    wave_lds_fence();
+    u64 k1[1] = {lane < cnt ? ws.q[lane] : 0ull};
+    wave_lds_fence();
+    bitonic_sort_desc<1>(k1, lane);
+    ws.key[0] = k1[0];
+    sorted = true;
+  } else if (!over) {
+    ws.cnt = cnt;
+    ws.flush();
+  } else {
+    for (int e0 = lane * 8; e0 - lane * 8 < L; e0 += 512) {  // (wave-uniform trip count)
+      const u32x4 ch = e0 < L ? *reinterpret_cast<const u32x4*>(rp + e0) : zero4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t word = ch[i >> 1];
+        const float v = __uint_as_float((i & 1) ? (word & 0xffff0000u) : (word << 16));
+        ws.offer(v >= ws.thr_val && v > 0.f, v, (unsigned)(e0 + i));
+      }
+    }
+    if (ws.cnt > 0) ws.flush();
+  }
+  if (!sorted) ws.finalize();
+  write_out<1, 4>(ws, svals, CLT_BF16, row, sidx, k);
+  const uint32_t bits = (uint32_t)(readlane_u64(ws.key[0], m - 1) >> 32);  // f32 pattern of the m-th value, 0 if there is none
+  if (lane == 0) tau[row] = bits == 0u ? __uint_as_float(1u) : __uint_as_float(bits - 0x8000u);
+}
+
 // Final selection of the fused path: one wave per token merges the sample's top-k (pass A) with the token's
 // candidate lists (pass B) under the same 64-bit key order as clt_topk_rows.  The threshold was the sample's m-th
 // value, m <= k: every element of the row that reaches it was collected, so the merged top-k is the row's top-k
@@ -805,12 +913,31 @@ int launch_fused_encode_topk(const FusedPlan& pl, const void* x, const void* W, 
   if (rc != CLT_OK) return rc;
   uint16_t* svals = (uint16_t*)(ws + pl.off_svals);
   int64_t* sidx = (int64_t*)(ws + pl.off_sidx);
-  rc = topk_rows_gated(ws + pl.off_pre_s, CLT_BF16, pl.lds, nullptr, nullptr, N, pl.Ls, k, svals, CLT_BF16, sidx, nullptr,
-                       0, st);
-  if (rc != CLT_OK) return rc;
   float* tau = (float*)(ws + pl.off_tau);
   const int64_t Npad = (int64_t)pl.ntt * GEMM_TN;
-  hipLaunchKernelGGL(tau_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, svals, k, pl.m, N, Npad, tau);
+  // register-resident rows: top-k and threshold in one launch.  Measured against the generic kernel + tau_kernel (same
+  // box, whole call): N = 65536, M = 12288, k = 32 (tp8 shard) 1.408 against 1.461 ms; C2 equal (1.065 / 1.063); k = 64
+  // at M = 131072 (~90 survivors: two queue merges, 78 registers) 3.263 against 3.222 ms -- so k <= 32 only.
+  if (pl.l16 && k <= 32 && pl.Ls <= 6144 && !(dbg & 128)) {
+    const dim3 sg((unsigned)(Npad / 4));
+    const uint16_t* pre_s = (const uint16_t*)(ws + pl.off_pre_s);
+    const int nch = (int)((pl.Ls + 511) / 512);
+#define CLT_SAMPLE_TOPK(NCH)                                                                                      \
+  hipLaunchKernelGGL((sample_topk_kernel<NCH>), sg, dim3(256), 0, st, pre_s, pl.lds, N, Npad, (int)pl.Ls, k, pl.m, svals, \
+                     sidx, tau)
+    if (nch <= 4)
+      CLT_SAMPLE_TOPK(4);
+    else if (nch <= 8)
+      CLT_SAMPLE_TOPK(8);
+    else
+      CLT_SAMPLE_TOPK(12);
+#undef CLT_SAMPLE_TOPK
+  } else {
+    rc = topk_rows_gated(ws + pl.off_pre_s, CLT_BF16, pl.lds, nullptr, nullptr, N, pl.Ls, k, svals, CLT_BF16, sidx,
+                         nullptr, 0, st);
+    if (rc != CLT_OK) return rc;
+    hipLaunchKernelGGL(tau_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, svals, k, pl.m, N, Npad, tau);
+  }
   // pass B: all other tiles, filtered against the thresholds
   FastArgs pb = a;
   pb.nlt = pl.nltB;

@@ -2,7 +2,7 @@
 // pre[N, M] = relu(x[N, d] @ W[M, d]^T + b) in bf16 on v_mfma_f32_16x16x32_bf16 whose epilogue keeps only the
 // accumulators that reach their token's threshold.
 //
-// Same workgroup tile, LDS image, LDS-DMA ring, product orientation (D[latent][token]) and candidate-list format as
+// Same workgroup tile, LDS image, LDS-DMA ring and product orientation (D[latent][token]) as the store-mode kernel of
 // encoder_gemm_fast16.hip, but the 256 x 256 tile is split over EIGHT waves (512 threads, 2 latent halves x 4 token
 // quarters, 128 latents x 64 tokens per wave) instead of four:
 //   * a wave holds 128 accumulators instead of 256, and at 256 registers per lane hipcc keeps them in ARCHITECTURAL
@@ -15,6 +15,16 @@
 //     what the LDS array delivers at the ideal MFMA rate (256 B/clk for ds_read_b128).
 // The accumulation order per output element is the four-wave kernel's (bias MFMA, then the k-steps in order), so the
 // accumulators -- and with them the fused path's results -- are bit-identical.
+//
+// What leaves the kernel is a CANDIDATE STREAM, not per-(token, group) lists: a hit (4 consecutive latents of one token
+// with at least one value at the threshold) becomes one 16-byte entry {2 x bf16, 2 x bf16, token, first latent}, appended
+// by the lanes that hit (rank = mbcnt of the hit mask under EXEC = hit mask, one ds_write_b128) to a wave-private LDS
+// queue of QCAP8 entries; a queue holding 64 or more entries at the end of a latent row is written out as dense 1 KiB
+// rows to the wave's own region of the global stream (region = 8 * workgroup + wave, FastArgs.stream_rcap entries), the
+// final count to FastArgs.stream_counts.  No atomics, no per-token list that could overflow: a region that runs full or
+// a queue that cannot take a row's worst case (64 more entries) flags its token tile for the fallback (fb_flags), which
+// no shape of BASELINE.json and no dictionary of tools/bench_fused.py reaches.  fused_bucket_kernel
+// (encoder_gemm_fast.hip) turns the stream into per-token lists for the merge.
 // MFMA-bound: 2 * N * M * d flops per launch.
 #include <math.h>
 

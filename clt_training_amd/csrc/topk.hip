@@ -83,12 +83,12 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const VT* __restrict__ v
 
   if constexpr (WPR == 4) {
     // tree merge through LDS: (0,1) and (2,3), then (0,2)
-    volatile u64* mine = lds_m[wave];
+    lds_u64* mine = (lds_u64*)lds_m[wave];
 #pragma unroll
     for (int r = 0; r < S; ++r) mine[r * 64 + lane] = ws.key[r];
     __syncthreads();
     if ((wave & 1) == 0) {
-      merge_from<S, R>(ws, lds_m[wave + 1]);
+      merge_from<S, R>(ws, (const lds_u64*)lds_m[wave + 1]);
     }
     __syncthreads();
     if (wave == 2) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const VT* __restrict__ v
     }
     __syncthreads();
     if (wave == 0) {
-      merge_from<S, R>(ws, lds_m[2]);
+      merge_from<S, R>(ws, (const lds_u64*)lds_m[2]);
       write_out<S, R>(ws, out_vals, out_dtype, row, out_idx, k);
     }
   } else {

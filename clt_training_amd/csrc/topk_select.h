@@ -6,6 +6,16 @@
 namespace clt {
 
 typedef unsigned long long u64;
+// The per-wave queue lives in LDS and is addressed as LDS: through a generic `volatile u64*` every append compiled to
+// flat_store_dwordx2 + s_waitcnt vmcnt(0) (LLVM keeps volatile accesses flat and completes each one), a full memory
+// round trip per offered element in every selection kernel.
+typedef __attribute__((address_space(3))) u64 lds_u64;
+// Orders this wave's LDS accesses for the compiler and the hardware (LDS executes a wave's operations in order; the wait
+// covers the returning reads).
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ u64 shfl_xor_u64(u64 x, int mask) {
   unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
@@ -83,7 +93,7 @@ struct WaveSelect {
   u64 thr_key;
   float thr_val;
   int cnt;
-  volatile u64* q;  // this wave's LDS queue [C]
+  lds_u64* q;  // this wave's LDS queue [C]
   int lane, k;
   int vlo, lob, nsel;
 
@@ -93,7 +103,7 @@ struct WaveSelect {
     thr_key = 0;
     thr_val = 0.f;
     cnt = 0;
-    q = queue;
+    q = (lds_u64*)(u64*)queue;
     lane = lane_;
     k = k_;
     vlo = 32;
@@ -108,14 +118,13 @@ struct WaveSelect {
   }
 
   __device__ __forceinline__ void flush() {
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's queue writes have landed
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();  // this wave's queue writes are ordered before the reads
 #pragma unroll
     for (int r = S; r < R; ++r) {
       const int e = (r - S) * 64 + lane;
       key[r] = e < cnt ? q[e] : 0ull;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
     if constexpr (!RX) {
       bitonic_sort_desc<R>(key, lane);
       thr_key = element_at<R>(key, k - 1);
@@ -147,14 +156,13 @@ struct WaveSelect {
         if (sel) q[pos] = key[r];
         base += __popcll(m);
       }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int e = r * 64 + lane;
         key[r] = (r < S && e < base) ? q[e] : 0ull;
       }
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
       nsel = base;
       thr_key = nz >= k ? T : 0ull;
     }
@@ -178,11 +186,10 @@ struct WaveSelect {
 #pragma unroll
       for (int r = 0; r < S; ++r)
         if (r * 64 + lane < nsel) q[S * 64 + rank[r]] = key[r];
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < S; ++r) key[r] = r * 64 + lane < nsel ? q[S * 64 + r * 64 + lane] : 0ull;
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
     }
   }
 
@@ -204,7 +211,7 @@ struct WaveSelect {
 
 // Load the top list of another wave (written as [S*64] keys) into regs [S, 2S) and re-sort.
 template <int S, int R>
-__device__ __forceinline__ void merge_from(WaveSelect<S, R>& ws, const volatile u64* other) {
+__device__ __forceinline__ void merge_from(WaveSelect<S, R>& ws, const lds_u64* other) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (r >= S && r < 2 * S) ws.key[r] = other[(r - S) * 64 + ws.lane];

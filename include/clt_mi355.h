@@ -96,12 +96,14 @@ int clt_candidates_unpack(const int64_t* packed, int64_t groups, int64_t rows, i
 /* Encoder GEMM + bias + ReLU + row top-k in one call (whole of fused_encoder.py:310-322,372 for
  * activation="topk"); results are those of clt_encoder_gemm_relu -> clt_topk_rows bit for bit.
  * `workspace`: clt_encode_topk_workspace_bytes(N, M, out_dtype) bytes = room for the pre-activation matrix
- * [N,M] in out_dtype + a 4 KiB tail that holds a device-side fallback flag.  bf16 operands with
- * M >= 320 k never form that matrix: the same bytes hold, laid over its front, the sample matrix
- * [N, M/S], the sample's top-k (values, int64 indices), the per-token thresholds tau[N], and the
- * candidate lists (8 x u32 per token and 64 latents -- per 32 latents where the 16x16x32 MFMA kernel runs: d % 64 == 0,
- * d >= 128, M % 16 == 0, which also keeps a k-step-major copy of x there) with their u8 lengths; the full matrix is written only
- * by the device-gated fallback launches (a candidate list overflowed or a token failed verification).
+ * [N,M] in out_dtype, plus max(1/8 of that, 8 KiB per token), plus a tail that holds the device-side fallback
+ * flags (one per 256-token tile).  bf16 operands with M >= 80 k never form that matrix: the same bytes hold, laid
+ * over its front, the sample matrix [N, M/S], the sample's top-k (values, int64 indices), the per-token thresholds
+ * tau[N] and the candidates -- where the 16x16x32 MFMA kernels run (d % 64 == 0, d >= 128, M % 16 == 0: every
+ * BASELINE width) a k-step-major copy of x, the candidate stream of the filter pass (16-byte entries, one region per
+ * wave of the launch) and the per-token candidate lists built from it; on other shapes 8 x u32 list slots per token
+ * and 64 latents with u8 lengths.  The full matrix is written only by the device-gated fallback launches (a token
+ * failed verification or a candidate buffer ran full: only the 256-token tiles concerned are redone).
  * Other dtypes / shapes: GEMM into the workspace, then clt_topk_rows over it.  Contents are scratch:
  * nothing in the workspace needs to survive the call, and calls sharing a workspace must be stream-ordered. */
 size_t clt_encode_topk_workspace_bytes(int64_t N, int64_t M, int out_dtype);

@@ -1,5 +1,6 @@
-"""Same-process A/B of the fused encode + top-k call with the filter pass on eight waves (default) and on four
-(CLT_GEMM_DEBUG=128), interleaved rounds, -DCLT_TUNING library (CLT_LIB=.../libcltmi355_tuning.so).  Prints the median
+"""Same-process A/B of the fused encode + top-k call under the tuning switches of the -DCLT_TUNING library
+(CLT_LIB=.../libcltmi355_tuning.so): --arms lists CLT_GEMM_DEBUG values, interleaved rounds (0 = as shipped, 128 = the
+sample's top-k through the generic clt_topk_rows kernel + tau_kernel instead of sample_topk_kernel).  Prints the median
 and the minimum of each arm in ms per call and the TFLOP/s of the faster figure."""
 import argparse
 import os
