@@ -754,7 +754,7 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
   if (grid <= 0) return CLT_OK;
   if (gemm_fast16_ok(a.M, a.kbytes) && !(a.dbg & 64)) {  // (-DCLT_TUNING builds: CLT_GEMM_DEBUG 64 = the 32x32x16 kernels)
     if (a.ngroups <= 0) a.ngroups = (int)(a.M / 16);  // every group of W (M % 16 == 0 here)
-    if (filter) return launch_gemm_w8_filter(a, grid, st);  // eight waves, slot-per-row candidate lists
+    if (filter) return launch_gemm_w8_filter(a, grid, st);  // eight waves, candidate stream (encoder_gemm_w8.hip)
     return launch_gemm_fast16(a, out_dtype, grid, st);
   }
   if (filter)
@@ -771,11 +771,10 @@ int launch_gemm_fast(FastArgs a, int out_dtype, bool filter, int cus, hipStream_
 FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, int k, int cus) {
   FusedPlan pl = {};
   if (!gemm_fast_supported(in_dtype, N, M, d) || out_dtype != CLT_BF16 || k < 1 || k > 256) return pl;
-  // Sample stride: pass A (store mode, ~1.7x the cost per tile of the filter mode, plus a row top-k over M / S columns)
-  // wants S large; the candidate lists (FUSED_SLOTS entries per 64 latents) want the expected 64 * m * S / M entries per
-  // list small.  An overflowing list costs only its 256-token tile's fallback (~1/ntt of a plain pass), so lists may run
-  // at ~1 expected entry (P(> 8) ~ 1e-6 per list): S up to M / (40 k).  Latent shards (M / tp rows) therefore still take
-  // the fused path: M = 12288, k = 32 -> S = 9 (was 2); M = 16384, k = 64 -> S = 6 (was unfused).
+  // Sample stride: pass A (store mode, ~1.4x the cost per tile of the filter mode, plus a row top-k over M / S columns)
+  // wants S large; the candidates (~m * S per token: filter epilogue, bucket and merge kernels) want it small.  S up to
+  // M / (40 k), capped at 16 (swept again on the eight-wave kernel: 12 / 16 / 20 / 24 / 32, 16 stays).  Latent shards
+  // (M / tp rows) still take the fused path: M = 12288, k = 32 -> S = 9; M = 16384, k = 64 -> S = 6.
   int64_t S = M / (tuning_env("CLT_FUSED_SDIV", 40) * (int64_t)k);
   const int64_t s_cap = tuning_env("CLT_FUSED_SCAP", 16);  // -DCLT_TUNING builds only
   if (S > s_cap) S = s_cap;
@@ -826,8 +825,8 @@ FusedPlan fused_plan(int in_dtype, int out_dtype, int64_t N, int64_t M, int d, i
       break;
     }
   }
-  // hit groups per lane and tile of the filter pass: 4 lists x 64 latents x (m S / M) candidates per latent.  The queue
-  // holds 9 per lane between flushes; P(Poisson(0.6) >= 10) ~ 1e-9 per lane and tile
+  // (32x32x16 filter kernel only) hit groups per lane and tile: 4 lists x 64 latents x (m S / M) candidates per latent.
+  // Its queue holds 9 per lane between flushes; P(Poisson(0.6) >= 10) ~ 1e-9 per lane and tile
   pl.qflush = 256.0 * pl.m * (double)S / (double)M > 0.6 ? 1 : 0;
   pl.nltA = (int)nltA;
   pl.nltB = (int)nltB;
