@@ -125,7 +125,10 @@ def test_encoder_gemm_kernels_use_no_scratch():
 
     from clt_training_amd.build import CSRC, FLAGS, HIPCC
 
-    for src, kernels in (("encoder_gemm_w8.hip", ("gemm_w8_filter_kernel",)), ("encoder_gemm_fast16.hip", ("gemm_fast16_kernel",))):
+    # (sample_topk_kernel keeps a whole row in registers through fully unrolled loops: a version whose loops hipcc
+    # declined to unroll indexed the row dynamically and put it in scratch, 208 bytes per lane)
+    for src, kernels in (("encoder_gemm_w8.hip", ("gemm_w8_filter_kernel",)), ("encoder_gemm_fast16.hip", ("gemm_fast16_kernel",)),
+                         ("encoder_gemm_fast.hip", ("sample_topk_kernel",))):
         out = subprocess.run([HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(CSRC / src), "-o", "/dev/null"],
                              capture_output=True, text=True, check=True).stderr
         blocks = re.split(r"remark: Function Name: ", out)[1:]
