@@ -634,6 +634,20 @@ def test_fused_encode_topk_holds_on_a_tile_correlated_dictionary(ops, rho):
     assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fused_encode_topk_random_shapes(ops, seed):
+    """tools/fuzz_fused.py: 30 random (N, M, d, k, bias dtype, data kind) cases per seed -- ragged N, M at and around the
+    fused path's limit (M = 80 k), widths with and without the 16x16x32 kernels, integer-valued operands with exact ties,
+    rows with fewer than k positives -- each bit-identical to GEMM + row top-k."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from tools.fuzz_fused import run
+
+    assert run(30, seed, verbose=False) == 0
+
+
 # --------------------------------------------------------------------------- FVU
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("masked", [False, True])
