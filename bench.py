@@ -80,7 +80,7 @@ class SimComm:
         return t
 
 
-def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.0):
+def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.0, adam_bytes=None):
     """Algorithmic flops / bytes per launch -> (amount, 'flop'|'byte').
     N = tokens of the whole group, M = latents of this rank, k / world = entries a rank owns per token and source;
     pairs_per_target = mean number of live sources per target launch ((L + 1) / 2 with cross_layer = L)."""
@@ -102,8 +102,8 @@ def algorithmic_work(name, N, d, M, k, es, P_total, world=1, pairs_per_target=1.
         return es * (M * d + N * k / world * d), "byte"
     if name in ("clt_spt_dense_adam", "clt_spt_dense_adam_multi"):  # gathered rows + read/write of the parameter, exp_avg and exp_avg_sq rows (per job)
         return es * (6 * M * d + N * k / world * d), "byte"
-    if name == "clt_adam_step":
-        return 7.0 * es * P_total, "byte"
+    if name == "clt_adam_step":  # p, g, exp_avg, exp_avg_sq read + p, exp_avg, exp_avg_sq written, each in the parameter's dtype
+        return 7.0 * (adam_bytes if adam_bytes is not None else es * P_total), "byte"
     if name == "clt_fvu_fwd_bwd":
         return N * d * es * 6, "byte"
     return None, None
@@ -270,7 +270,9 @@ def main():
     P_total = sum(p.numel() for sae in trainer.saes.values() for p in sae.parameters())
     # parameters that still go through clt_adam_step: everything but the [M, d] matrices when their update is fused
     fused = getattr(getattr(trainer, "engine", None), "fused_opt", None) is not None or getattr(trainer, "_fused", False)
-    P_adam = sum(p.numel() for sae in trainer.saes.values() for p in sae.parameters() if not (fused and p.dim() == 2 and p.shape[0] > d))
+    small = [p for sae in trainer.saes.values() for p in sae.parameters() if not (fused and p.dim() == 2 and p.shape[0] > d)]
+    P_adam = sum(p.numel() for p in small)
+    B_adam = sum(p.numel() * p.element_size() for p in small)  # (biases, skips and post-encoder vectors are fp32)
 
     real_world = int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -313,7 +315,7 @@ def main():
         kernels = {}
         dominant, dom_ms = None, -1.0
         for name, (cnt, ms) in prof.summary().items():
-            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_adam, world, 1.0 if args.sae else (L + 1) / 2)
+            amount, kind = algorithmic_work(name, tokens_per_step, d, Ml, k, es, P_adam, world, 1.0 if args.sae else (L + 1) / 2, B_adam)
             if amount is not None and name in prof.units:  # batched entry point: pairs per launch, counted live
                 amount *= prof.units[name] / cnt
             ent = {"launches_per_step": cnt / sampled, "mean_ms": round(ms, 4),
