@@ -31,6 +31,7 @@ RULES = [
     ("fused_select_kernel", "", "fused_select_kernel"),
     ("fused_bucket_kernel", "", "fused_bucket_kernel"),
     ("gemm_w8_filter_kernel", "", "gemm_w8_filter_kernel"),
+    ("sample_topk_kernel", "", "clt_topk_rows(sample)"),  # (round 3: the register-resident sample top-k + threshold)
     ("topk_rows_kernel", "", "clt_topk_rows(sample)"),
     ("adam_kernel", "", "clt_adam_step"),
     ("pack_x_kernel", "", "pack_x_kernel"),
