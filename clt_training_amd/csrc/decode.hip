@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(const int64_t* __restri
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int ch = lane + 64 * c;
-          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+          raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)(ch < nchunks ? ch : nchunks - 1) * 16);  // (unconditional: rows_lds_row, spt_rows.h)
         }
       }
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int ch = lane + 64 * c;
-          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+          raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)(ch < nchunks ? ch : nchunks - 1) * 16);  // (unconditional: rows_lds_row, spt_rows.h)
         }
       }
 #pragma unroll
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void decode_fwd_multi_kernel(const SrcTable ta
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int ch = lane + 64 * c;
-          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+          raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)(ch < nchunks ? ch : nchunks - 1) * 16);  // (unconditional: rows_lds_row, spt_rows.h)
         }
       }
 #pragma unroll
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_multi_kernel(const SrcTab
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int ch = lane + 64 * c;
-          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+          raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)(ch < nchunks ? ch : nchunks - 1) * 16);  // (unconditional: rows_lds_row, spt_rows.h)
         }
       }
 #pragma unroll
@@ -734,7 +734,9 @@ __global__ __launch_bounds__(256) void decode_fwd_multi_lds_kernel(const SrcTabl
       my_a = permute_push_f(dest, my_a);
       cnt = nv;
     }
-    // (the scalar loads above are done: their results fed the address computation; the counted waits below see DMAs only)
+    // (the scalar loads above are done: their results fed the address computation; the counted waits below see DMAs only.
+    // Requesting the NEXT group's index and activation here, to have them in flight under this group's rows, was measured
+    // in round 3: 413 -> 416 us per launch at C2, no gain -- twelve waves per CU hide the header already.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     auto issue = [&](int jj0, int half) {
 #pragma unroll

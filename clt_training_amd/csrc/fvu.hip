@@ -5,6 +5,8 @@
 // HBM-bound, algorithmic bytes ~ N*d*(3*sizeof(y) + 2*sizeof(yhat) + sizeof(G)).
 #include <mutex>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace clt {
@@ -27,15 +29,24 @@ static int fvu_blocks(int64_t N) {
 
 __device__ __forceinline__ float ld(const void* p, int dt, int64_t i) { return load_scalar(p, dt, i); }
 
-// 4 consecutive elements starting at element i (i % 4 == 0, 16-byte aligned base)
-__device__ __forceinline__ void ld4(const void* p, int dt, int64_t i, float (&f)[4]) {
-  if (dt == CLT_BF16) {
+// 4 consecutive elements starting at element i (i % 4 == 0, 16-byte aligned base), dtype known at compile time.
+// (A version with the dtype as a runtime argument was called from inside the loops below until round 3: with the runtime
+// branch of ld4 inside an unrolled loop every load sat in a conditional block of its own and hipcc put `s_waitcnt vmcnt(0)`
+// in front of each -- eight serialised memory round trips per unrolled iteration instead of eight loads in flight.)
+template <bool BF>
+__device__ __forceinline__ void ld4t(const void* p, int64_t i, float (&f)[4]) {
+  if constexpr (BF) {
     const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + i);
     f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
   } else {
     const float4 u = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
     f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w;
   }
+}
+template <typename F>
+__device__ __forceinline__ void by_dtype(int dt, F&& f) {
+  if (dt == CLT_BF16) f(std::true_type{});
+  else f(std::false_type{});
 }
 
 // grid = (row blocks, column blocks of 1024): four columns per thread, a row block's rows in order
@@ -47,14 +58,16 @@ __global__ __launch_bounds__(256) void fvu_colsum_kernel(const void* __restrict_
   const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (c < d) {
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    by_dtype(y_dtype, [&](auto yb) {
 #pragma unroll 8
-    for (int64_t r = r0; r < r1; ++r) {
-      const bool m = mask ? mask[r] != 0 : true;
-      float v[4];
-      ld4(y, y_dtype, r * d + c, v);
+      for (int64_t r = r0; r < r1; ++r) {
+        const bool m = mask ? mask[r] != 0 : true;
+        float v[4];
+        ld4t<decltype(yb)::value>(y, r * d + c, v);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s[q] += m ? v[q] : 0.f;
-    }
+        for (int q = 0; q < 4; ++q) s[q] += m ? v[q] : 0.f;
+      }
+    });
     *reinterpret_cast<float4*>(pcol + (int64_t)blockIdx.x * d + c) = make_float4(s[0], s[1], s[2], s[3]);
   }
   if (blockIdx.y == 0 && threadIdx.x == 0) {
@@ -121,20 +134,24 @@ __global__ __launch_bounds__(256) void fvu_partial_kernel(const void* __restrict
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
     const float4 mu4 = *reinterpret_cast<const float4*>(mean + c);
     const float mu[4] = {mu4.x * inv_cnt, mu4.y * inv_cnt, mu4.z * inv_cnt, mu4.w * inv_cnt};
+    by_dtype(y_dtype, [&](auto yb) {
+      by_dtype(yh_dtype, [&](auto hb) {
 #pragma unroll 8
-    for (int64_t r = r0; r < r1; ++r) {
-      const bool m = mask ? mask[r] != 0 : true;
-      float yy[4], yh[4];
-      ld4(y, y_dtype, r * d + c, yy);
-      ld4(yhat, yh_dtype, r * d + c, yh);
+        for (int64_t r = r0; r < r1; ++r) {
+          const bool m = mask ? mask[r] != 0 : true;
+          float yy[4], yh[4];
+          ld4t<decltype(yb)::value>(y, r * d + c, yy);
+          ld4t<decltype(hb)::value>(yhat, r * d + c, yh);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float e = m ? yy[q] - yh[q] : 0.f;
-        const float dv = m ? yy[q] - mu[q] : 0.f;
-        l2 = fmaf(e, e, l2);
-        tv = fmaf(dv, dv, tv);
-      }
-    }
+          for (int q = 0; q < 4; ++q) {
+            const float e = m ? yy[q] - yh[q] : 0.f;
+            const float dv = m ? yy[q] - mu[q] : 0.f;
+            l2 = fmaf(e, e, l2);
+            tv = fmaf(dv, dv, tv);
+          }
+        }
+      });
+    });
   }
   l2 = wave_sum(l2);
   tv = wave_sum(tv);
@@ -178,23 +195,27 @@ __global__ __launch_bounds__(256) void fvu_grad_kernel(const void* __restrict__ 
   if (!G) return;
   const float coef = -2.f * gscale / tv;
   const int64_t total = N * (int64_t)d;
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
-    const int64_t r = i / d;  // d % 4 == 0: the 4 elements share a row
-    const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
-    float g[4], yy[4], yh[4];
-    ld4(y, y_dtype, i, yy);
-    ld4(yhat, yh_dtype, i, yh);
+  by_dtype(y_dtype, [&](auto yb) {
+    by_dtype(yh_dtype, [&](auto hb) {
+      for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+        const int64_t r = i / d;  // d % 4 == 0: the 4 elements share a row
+        const float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
+        float g[4], yy[4], yh[4];
+        ld4t<decltype(yb)::value>(y, i, yy);
+        ld4t<decltype(hb)::value>(yhat, i, yh);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) g[q] = coef * m * (yy[q] - yh[q]);
-    if constexpr (sizeof(GT) == 2) {
-      uint2 u;
-      u.x = pack_bf16x2(g[0], g[1]);
-      u.y = pack_bf16x2(g[2], g[3]);
-      *reinterpret_cast<uint2*>(G + i) = u;
-    } else {
-      *reinterpret_cast<float4*>(G + i) = make_float4(g[0], g[1], g[2], g[3]);
-    }
-  }
+        for (int q = 0; q < 4; ++q) g[q] = coef * m * (yy[q] - yh[q]);
+        if constexpr (sizeof(GT) == 2) {
+          uint2 u;
+          u.x = pack_bf16x2(g[0], g[1]);
+          u.y = pack_bf16x2(g[2], g[3]);
+          *reinterpret_cast<uint2*>(G + i) = u;
+        } else {
+          *reinterpret_cast<float4*>(G + i) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+      }
+    });
+  });
 }
 
 }  // namespace clt

@@ -288,12 +288,15 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
     if (pos < end) {
       const int e = perm[pos];
       my_e = e;
+      uint32_t v_raw = 0, g_raw = 0;  // (every load issued before any is converted: rows_lds_row)
       if constexpr (BWD) {
-        my_v = load_scalar(bw.v, bw.v_dtype, e);
+        v_raw = load_scalar_word(bw.v, bw.v_dtype, e);
         my_u = bw.grad_acts[e];  // fetched with the entry: only a store is left at the end of the chunk
       }
       float w = vals[e];
-      if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
+      if (gate) g_raw = load_scalar_word(gate, gate_dtype, e);
+      if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v_dtype, e);
+      if (gate) w = scalar_from_word(g_raw, gate_dtype, e) > 0.f ? w : 0.f;
       my_w = w;
       my_n = entry_token(e, k);
 #pragma unroll
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int ch = lane + 64 * c;
-          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)ch * 16);
+          raw[u][c] = *reinterpret_cast<const uint4*>(row + (size_t)(ch < nchunks ? ch : nchunks - 1) * 16);  // (unconditional: rows_lds_row, spt_rows.h)
         }
       }
 #pragma unroll
@@ -475,12 +478,15 @@ __device__ __forceinline__ void rows_long_block(const int32_t* __restrict__ perm
       if (pos < end) {
         const int e = perm[pos];
         my_e = e;
+        uint32_t v_raw = 0, g_raw = 0;  // (every load issued before any is converted: rows_lds_row)
         if constexpr (BWD) {
-          my_v = load_scalar(bw.v, bw.v_dtype, e);
+          v_raw = load_scalar_word(bw.v, bw.v_dtype, e);
           my_u = bw.grad_acts[e];
         }
         float w = vals[e];
-        if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
+        if (gate) g_raw = load_scalar_word(gate, gate_dtype, e);
+        if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v_dtype, e);
+        if (gate) w = scalar_from_word(g_raw, gate_dtype, e) > 0.f ? w : 0.f;
         my_w = w;
         my_n = entry_token(e, k);
       }
@@ -495,7 +501,7 @@ __device__ __forceinline__ void rows_long_block(const int32_t* __restrict__ perm
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
             const int ch = lane + 64 * c;
-            if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(grow + (size_t)ch * 16);
+            raw[u][c] = *reinterpret_cast<const uint4*>(grow + (size_t)(ch < nchunks ? ch : nchunks - 1) * 16);  // (unconditional: rows_lds_row, spt_rows.h)
           }
         }
 #pragma unroll
@@ -664,12 +670,16 @@ __device__ __forceinline__ void rows_lds_row(
     if (pos < end) {
       const int e = perm[pos];
       my_e = e;
+      // the entry's scalars: every load is issued before any is converted (one memory round trip, not one per array)
+      uint32_t v_raw = 0, g_raw = 0;
       if constexpr (BWD) {
-        my_v = load_scalar(bw.v, bw.v_dtype, e);
+        v_raw = load_scalar_word(bw.v, bw.v_dtype, e);
         my_u = bw.grad_acts[e];  // fetched with the entry: only a store is left at the end of the chunk
       }
       float w = vals[e];
-      if (gate) w = load_scalar(gate, gate_dtype, e) > 0.f ? w : 0.f;
+      if (gate) g_raw = load_scalar_word(gate, gate_dtype, e);
+      if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v_dtype, e);
+      if (gate) w = scalar_from_word(g_raw, gate_dtype, e) > 0.f ? w : 0.f;
       my_w = w;
       my_n = entry_token(e, k);
     }
@@ -681,10 +691,14 @@ __device__ __forceinline__ void rows_lds_row(
         const int jl = min(jj + u, cnt - 1);
         const int n = readlane_i(my_n, jl);
         const char* grow = reinterpret_cast<const char*>(dense) + (size_t)n * (size_t)d * sizeof(T);
+        // Unconditional loads (lanes past the row's last chunk re-read it: same cache line, no traffic).  With the load
+        // under `if (ch < nchunks)` every load sat in an EXEC-masked block of its own, and from the second batch of a
+        // segment on hipcc put `s_waitcnt vmcnt(0)` in front of each (the destination registers of the previous
+        // batch "may" still be pending on the path that skipped their use): eight serialised round trips per batch.
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int ch = lane + 64 * c;
-          if (ch < nchunks) raw[u][c] = *reinterpret_cast<const uint4*>(grow + (size_t)ch * 16);
+          raw[u][c] = *reinterpret_cast<const uint4*>(grow + (size_t)(ch < nchunks ? ch : nchunks - 1) * 16);
         }
       }
       if constexpr (BWD) {
