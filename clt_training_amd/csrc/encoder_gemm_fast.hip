@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const uint16_t* __rest
                                                           uint16_t* __restrict__ svals, int64_t* __restrict__ sidx,
                                                           float* __restrict__ tau) {
   __shared__ u64 lds_q[4][192];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: the token's scalars are scalar loads)
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= Npad) return;
   if (row >= N) {
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void fused_select_kernel(const uint16_t* __res
                                                            int64_t* __restrict__ out_idx, int* __restrict__ flag) {
   constexpr int C = (R - S) * 64;
   __shared__ u64 lds_q[4][C];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: the token's scalars are scalar loads)
   const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
   if (tok >= N) return;
   WaveSelect<S, R, (S <= 2)> ws;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void fused_select_stream_kernel(const uint16_t
                                                                   int64_t* __restrict__ out_idx, int* __restrict__ flag) {
   constexpr int C = (R - S) * 64;
   __shared__ u64 lds_q[4][C];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: the token's scalars are scalar loads)
   const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
   if (tok >= N) return;
   WaveSelect<S, R, (S <= 2)> ws;

@@ -600,7 +600,10 @@ __device__ __forceinline__ void rows_lds_row(
     float* __restrict__ rowsum, const AdamRows& ad, const BwdActs& bw, const LongRows& lr) {
   constexpr int E = Chunk<T>::E;  // 16-byte chunks of the state rows and of the dense rows alike
   extern __shared__ __attribute__((aligned(16))) char rows_lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave number through readfirstlane: everything indexed by the row -- its segment bounds, its post-encoder
+  // scalars -- is then a scalar load, ~a quarter of a vector load's latency at the head of the wave's dependent chain
+  // bounds -> perm -> entry scalars -> gathered rows)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row = (int64_t)blockIdx.x * 2 + wave;
   if (row >= M) return;
   const int nchunks = d / E;
@@ -609,7 +612,7 @@ __device__ __forceinline__ void rows_lds_row(
   char* my_lds = rows_lds + (size_t)wave * NARR * rowbytes;
   // (wave-uniform, but hipcc cannot know: readfirstlane puts it in an SGPR for the m0 moves)
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void_ptr)my_lds);
-  const int my_off = lane < 2 ? offsets[row + lane] : 0;
+  const int beg = offsets[row], end = offsets[row + 1];
   const int64_t roff = row * (int64_t)d;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {  // [p, m, v][chunk], chunk-linear
@@ -625,7 +628,6 @@ __device__ __forceinline__ void rows_lds_row(
       }
     }
   }
-  const int beg = readlane_i(my_off, 0), end = readlane_i(my_off, 1);
 
   float acc[CH][E];
 #pragma unroll
@@ -702,7 +704,10 @@ __device__ __forceinline__ void rows_lds_row(
         }
       }
       if constexpr (BWD) {
-        if (!staged) {  // the row's first entries: the parameter row (before its update) out of LDS
+        // the row's first entries: the parameter row (before its update) out of LDS.  (Taking it BEFORE the gather loads
+        // are requested -- the wait is free there -- was measured in round 3: 197 -> 206 us per pair; the LDS read then
+        // sits on the path to the gathers.)
+        if (!staged) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           staged = true;
 #pragma unroll

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const VT* __restrict__ v
   __shared__ u64 lds_q[4][C];
   __shared__ u64 lds_m[4][S * 64];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row = WPR == 4 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
   const int part = WPR == 4 ? wave : 0;
   if (WPR == 1 && row >= N) return;
