@@ -130,16 +130,18 @@ __device__ __forceinline__ float load_scalar(const void* p, int dtype, int64_t i
   return reinterpret_cast<const float*>(p)[i];
 }
 
-// load_scalar in two halves, for code that wants several such loads IN FLIGHT together: the 32-bit word that holds element
-// i (one load instruction whatever the dtype), and its conversion.  load_scalar's own dtype branch puts each load in a
-// block of its own with the conversion right behind it, so hipcc waits for every load before it issues the next.
-// (p is 4-byte aligned; for an odd number of bf16 elements the last word ends two bytes past them.)
+// load_scalar in two halves, for code that wants several such loads IN FLIGHT together: the aligned 32-bit word that holds
+// element i (one load instruction whatever the dtype), and its conversion.  load_scalar's own dtype branch puts each load
+// in a block of its own with the conversion right behind it, so hipcc waits for every load before it issues the next.
+// (A bf16 array needs no more than its natural 2-byte alignment: the word is taken at the element's address rounded
+// down, so at most two bytes before the first or after the last element are touched -- inside any allocation granule.)
 __device__ __forceinline__ uint32_t load_scalar_word(const void* p, int dtype, int64_t i) {
-  const int64_t b = dtype == CLT_BF16 ? ((i * 2) & ~(int64_t)3) : i * 4;
-  return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p) + b);
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p) + (uintptr_t)(dtype == CLT_BF16 ? i * 2 : i * 4);
+  return *reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
 }
-__device__ __forceinline__ float scalar_from_word(uint32_t w, int dtype, int64_t i) {
-  return __uint_as_float(dtype == CLT_BF16 ? ((i & 1) ? (w & 0xffff0000u) : (w << 16)) : w);
+__device__ __forceinline__ float scalar_from_word(uint32_t w, const void* p, int dtype, int64_t i) {
+  const bool hi = ((reinterpret_cast<uintptr_t>(p) >> 1) + (uintptr_t)i) & 1;
+  return __uint_as_float(dtype == CLT_BF16 ? (hi ? (w & 0xffff0000u) : (w << 16)) : w);
 }
 
 __device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) void spt_dense_kernel(const int32_t* __restric
       }
       float w = vals[e];
       if (gate) g_raw = load_scalar_word(gate, gate_dtype, e);
-      if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v_dtype, e);
-      if (gate) w = scalar_from_word(g_raw, gate_dtype, e) > 0.f ? w : 0.f;
+      if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v, bw.v_dtype, e);
+      if (gate) w = scalar_from_word(g_raw, gate, gate_dtype, e) > 0.f ? w : 0.f;
       my_w = w;
       my_n = entry_token(e, k);
 #pragma unroll
@@ -485,8 +485,8 @@ __device__ __forceinline__ void rows_long_block(const int32_t* __restrict__ perm
         }
         float w = vals[e];
         if (gate) g_raw = load_scalar_word(gate, gate_dtype, e);
-        if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v_dtype, e);
-        if (gate) w = scalar_from_word(g_raw, gate_dtype, e) > 0.f ? w : 0.f;
+        if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v, bw.v_dtype, e);
+        if (gate) w = scalar_from_word(g_raw, gate, gate_dtype, e) > 0.f ? w : 0.f;
         my_w = w;
         my_n = entry_token(e, k);
       }
@@ -680,8 +680,8 @@ __device__ __forceinline__ void rows_lds_row(
       }
       float w = vals[e];
       if (gate) g_raw = load_scalar_word(gate, gate_dtype, e);
-      if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v_dtype, e);
-      if (gate) w = scalar_from_word(g_raw, gate_dtype, e) > 0.f ? w : 0.f;
+      if constexpr (BWD) my_v = scalar_from_word(v_raw, bw.v, bw.v_dtype, e);
+      if (gate) w = scalar_from_word(g_raw, gate, gate_dtype, e) > 0.f ? w : 0.f;
       my_w = w;
       my_n = entry_token(e, k);
     }

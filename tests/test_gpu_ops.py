@@ -634,6 +634,31 @@ def test_fused_encode_topk_holds_on_a_tile_correlated_dictionary(ops, rho):
     assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
 
 
+def test_decode_bwd_rows_takes_two_byte_aligned_activations(ops):
+    """The row pass fetches an entry's bf16 activation as the aligned 32-bit word that holds it (one load instruction for
+    either dtype, so that all of an entry's scalars are in flight together): an activation array that starts at an odd
+    element -- 2-byte aligned, which the ABI allows -- must give the same bits as a 4-byte aligned copy."""
+    N, d, M, k = 700, 256, 2048, 16
+    g = torch.Generator().manual_seed(5)
+    W = (torch.randn(M, d, generator=g) / math.sqrt(d)).to(torch.bfloat16).to(DEV)
+    buf = torch.rand(N * k + 1, generator=g).to(torch.bfloat16).to(DEV)
+    v_odd = buf[1:].view(N, k)  # storage offset 1: contiguous, 2-byte aligned
+    v_even = v_odd.clone()
+    assert v_odd.data_ptr() % 4 == 2 and v_even.data_ptr() % 4 == 0 and v_odd.is_contiguous()
+    idx = torch.stack([torch.randperm(M, generator=g)[:k] for _ in range(N)]).to(DEV)
+    pe = (0.1 * torch.randn(M, generator=g)).to(DEV)
+    G = torch.randn(N, d, generator=g).to(torch.bfloat16).to(DEV)
+    seg = ops.segments_build(idx, M)
+    outs = []
+    for v in (v_even, v_odd):
+        _, acts = ops.decode_fwd(idx, v, W, post_enc=pe, want_acts=True)
+        ga = torch.zeros(N, k, device=DEV)
+        gW, gp, _ = ops.decode_bwd_rows(seg, acts.view(-1), v, W, G, ga, post_enc=pe, want_g_post=True)
+        outs.append((gW, gp, ga))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("seed", [0, 1])
 def test_fused_encode_topk_random_shapes(ops, seed):
     """tools/fuzz_fused.py: 30 random (N, M, d, k, bias dtype, data kind) cases per seed -- ragged N, M at and around the
