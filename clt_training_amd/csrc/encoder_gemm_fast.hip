@@ -690,6 +690,13 @@ __global__ __launch_bounds__(256) void fused_select_stream_kernel(const uint16_t
   const u32x4* lrow = tlists + tok * (int64_t)tcap;
   const u32x4 none = {0u, 0u, 0u, 0u};
   u32x4 ent = lane < n ? lrow[lane] : none;  // (in flight while the sample's entries are offered)
+  // The selection starts AT the token's threshold (the sample's m-th value): the result stands only if its k-th value
+  // reaches the threshold (the check below), and then nothing under the threshold is part of it -- not the sample's
+  // entries m + 1 .. k either.  Until round 3 all k sample entries were offered and merged first (one queue merge of
+  // ~480 instructions per token) to raise the selection's threshold to the sample's k-th value, which is lower.
+  const float thr_m = bf16_bits_to_f32(svals[tok * k + m - 1]);
+  ws.thr_val = thr_m;
+  ws.thr_key = thr_m > 0.f ? (((u64)__float_as_uint(thr_m)) << 32) - 1ull : 0ull;  // keys of value >= thr_m pass
   // the sample's best k: column c of the sample matrix is latent c % 16 of group (c / 16) S + S - 1 (grp_actual)
   for (int e0 = 0; e0 < k; e0 += 64) {
     const int e = e0 + lane;
@@ -700,9 +707,8 @@ __global__ __launch_bounds__(256) void fused_select_stream_kernel(const uint16_t
       const int64_t c = sidx[tok * k + e];
       col = (unsigned)grp_actual((int)(c >> 4), LT_GSAMPLE, lt_S) * 16u + (unsigned)(c & 15);
     }
-    ws.offer(v > 0.f, v, col);
+    ws.offer(v > 0.f && v >= thr_m, v, col);
   }
-  if (ws.cnt > 0) ws.flush();  // the threshold is now the sample's k-th value
   for (int e0 = 0; e0 < n; e0 += 64) {
     const u32x4 cur = ent;
     const bool have = e0 + lane < n;
@@ -715,7 +721,6 @@ __global__ __launch_bounds__(256) void fused_select_stream_kernel(const uint16_t
     }
   }
   ws.flush();
-  const float thr_m = bf16_bits_to_f32(svals[tok * k + m - 1]);
   if (over || ws.thr_val < thr_m) {
     if (lane == 0) atomicOr(flag + 1 + tok / GEMM_TN, 1);  // this token's 256-token tile goes through the fallback
   }

@@ -136,16 +136,20 @@ struct WaveSelect {
       if (nz >= k) {
         // invariant: at least k keys are >= prefix.  Index bits [lob, 32) are ones in every real key.
         u64 prefix = lob < 32 ? (1ull << 32) - (1ull << lob) : 0ull;
+        int at_prefix = nz;  // number of keys >= prefix
         auto step = [&](int b) {
           const u64 t = prefix | (1ull << b);
           int c = 0;
 #pragma unroll
           for (int r = 0; r < R; ++r) c += __popcll(__ballot(key[r] >= t));
-          if (c >= k) prefix = t;
+          if (c >= k) prefix = t, at_prefix = c;
         };
         for (int b = 62; b >= vlo; --b) step(b);
-        for (int b = lob - 1; b >= 0; --b) step(b);
-        T = prefix;  // the k-th largest key (keys are distinct)
+        // exactly k keys reach the k-th VALUE: no tie to break at the boundary, every one of them is selected and the
+        // index bits need no search (half of the steps; the usual case)
+        if (at_prefix != k)
+          for (int b = lob - 1; b >= 0; --b) step(b);
+        T = prefix;  // the k-th largest key (keys are distinct), or a bound that exactly k keys reach
       }
       int base = 0;
 #pragma unroll
