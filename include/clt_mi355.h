@@ -209,7 +209,10 @@ int clt_segments_build(const int64_t* idx, int64_t n_entries, int64_t M, int64_t
  *               grad_b of fused_encoder.py:140-143)
  * vals [N*k] fp32; vals_gate [N*k] (`gate_dtype`) or NULL: when given, vals[e] is multiplied by
  * (vals_gate[e] > 0) -- the (values > 0) mask of fused_encoder.py:97; dense [N,d] `dense_dtype`;
- * out [M,d] `out_dtype`.  Atomic-free and bitwise reproducible.  n_entries / workspace: the optional long-segment
+ * out [M,d] `out_dtype`.  Atomic-free and bitwise reproducible.  (bf16 per-entry arrays -- vals_gate here, v of the
+ * decoder row passes -- are read as the aligned 32-bit word around the element: their natural 2-byte alignment is
+ * enough, and up to two bytes before the first / after the last element are touched, inside any allocation granule.)
+ * n_entries / workspace: the optional long-segment
  * pre-reduction described at clt_spt_dense_adam (workspace NULL, or dense_dtype != out_dtype: every row is walked
  * by one wave).                                                                                  */
 int clt_spt_dense(const int32_t* perm, const int32_t* offsets, int64_t M, const float* vals, const void* vals_gate,
