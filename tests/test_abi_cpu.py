@@ -141,3 +141,37 @@ def test_encoder_gemm_kernels_use_no_scratch():
                 spills = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
                 assert scratch == 0 and spills == 0, (src, name, scratch, spills)
         assert seen >= 1, (src, "kernel not found in the resource report")
+
+
+def test_hot_loops_do_not_wait_in_front_of_every_load():
+    """Round 3 found three kernels in which hipcc had put ``s_waitcnt vmcnt(0)`` directly in front of every load of a loop
+    (loads under a per-lane or a dtype branch: each sits in a block of its own and its destination register "may" still
+    be pending) -- the gathered rows of the row passes and the rows of the FVU kernels arrived one memory round trip
+    after another.  The ISA of those kernels must not show that pattern again."""
+    import re
+    import subprocess
+
+    from clt_training_amd.build import CSRC, FLAGS, HIPCC
+
+    def serialised_loads(src, kernel_substrings):
+        asm = subprocess.run([HIPCC, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / src)],
+                             capture_output=True, text=True, check=True).stdout.split("\n")
+        name, counts = None, {}
+        for i, line in enumerate(asm):
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                name = m.group(1)
+            if name and "s_waitcnt vmcnt(0)" in line:
+                nxt = [x for x in asm[i + 1:i + 4] if x.strip() and not x.strip().startswith(";")][:2]
+                if any("global_load" in x or "flat_load" in x for x in nxt):
+                    counts[name] = counts.get(name, 0) + 1
+        names = {m.group(1) for m in (re.match(r"^(_Z\w+):", ln) for ln in asm) if m}
+        seen = [n for n in names if any(k in n for k in kernel_substrings)]
+        assert seen, (src, "kernels not found")
+        return {n: counts.get(n, 0) for n in seen}
+
+    # (one or two such waits are legitimate: a dependent load behind the load of its index)
+    for src, kernels in (("decode_rows.hip", ("rows_lds_multi_kernelIDF16bLi2ELi4E", "rows_lds_kernelIDF16bLi2ELi4E")),
+                         ("fvu.hip", ("fvu_partial_kernel", "fvu_colsum_kernel", "fvu_grad_kernel"))):
+        for name, n in serialised_loads(src, kernels).items():
+            assert n <= 2, (src, name, n)
