@@ -763,6 +763,14 @@ __global__ __launch_bounds__(256) void decode_fwd_multi_lds_kernel(const SrcTabl
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      // every LDS read of the batch first (lanes past the row's last chunk re-read the slot's first bytes), then the FMAs:
+      // under `if (ch < nchunks)` each read sat in a block of its own, in ONE register quad, with its wait right behind it
+      uint4 raw[H][CH];
+#pragma unroll
+      for (int u = 0; u < H; ++u)
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          raw[u][c] = *reinterpret_cast<const uint4*>(my + (half * H + u) * SLOT + (lane + 64 * c < nchunks ? c * 1024 + lane * 16 : 0));
 #pragma unroll
       for (int u = 0; u < H; ++u) {
         const float a_u = (jj + u < cnt) ? readlane_f(my_a, min(jj + u, cnt - 1)) : 0.f;
@@ -770,9 +778,8 @@ __global__ __launch_bounds__(256) void decode_fwd_multi_lds_kernel(const SrcTabl
         for (int c = 0; c < CH; ++c) {
           const int ch = lane + 64 * c;
           if (ch < nchunks) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(my + (half * H + u) * SLOT + c * 1024 + lane * 16);
             float w[E];
-            Chunk<WT>::expand(raw, w);
+            Chunk<WT>::expand(raw[u][c], w);
 #pragma unroll
             for (int q = 0; q < E; ++q) acc[c][q] = fmaf(a_u, w[q], acc[c][q]);
           }
